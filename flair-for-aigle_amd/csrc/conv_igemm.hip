@@ -1,0 +1,505 @@
+// Implicit-GEMM convolution on MFMA for gfx950, NHWC, bf16 or f32 operands, f32 accumulate.
+//
+// Replaces the cuDNN/ATen conv2d reached through segmentation_models_pytorch from
+// flair_hub/models/monotemp_model.py:68-92 (encoder/decoder conv stack called at
+// flair_hub/models/flair_model.py:376 and :417-419).  The same kernel serves
+//   * forward conv (3x3 s1/s2, 1x1 s1/s2, 7x7 s2) with fused bias / residual add / ReLU epilogue
+//   * dgrad: a stride-1 conv over dy with flipped+transposed packed weights; for stride-2
+//     layers dy is read through a virtual zero-insertion (dil = 2), never materialised.
+//
+// GEMM orientation: D[co][pixel] = W[co][k] * X[k][pixel], k = (tap, channel).  Weights are the
+// MFMA A operand (rows), pixels the B operand (columns), so every lane ends up holding runs of
+// consecutive output channels of ONE pixel -> 16-byte NHWC stores without an LDS transpose.
+//
+// Per block: BCO output channels x (TH x TW) output pixels of one image.  Per chunk (one 32-byte
+// k-step of input channels, RG kernel rows): the input halo tile and the weight slab are staged
+// global -> registers -> LDS (zero fill for padding / zero-insertion happens in registers), the
+// next chunk's global loads are issued before the MFMAs of the current one.
+// LDS images:  halo  [IH*IW pixels][32 B + 16 B pad]  (pitch 48 B: conflict-free ds_read_b128
+//                     for 16 consecutive pixels, 3 is coprime with the 16 slots of a bank row)
+//              weight [BCO rows][TAPS*32 B + 16 B pad] (odd number of 16-B slots per row)
+#include "ffa_common.h"
+
+struct ConvArgs {
+  const void* in;
+  const void* w;
+  void* out;
+  const float* bias;  // [>= co block coverage] or null
+  const void* res;    // same layout as out, or null
+  int B, Hi, Wi, Ci;  // stored input dims (Ci = channel pitch)
+  int Ho, Wo, Co;     // Co = stored output channel pitch
+  int pad, dil, relu;
+  int nchunks;  // Ci * sizeof(T) / 32
+  int tiles_x, tiles_y, npt, ncb;
+};
+
+template <typename T>
+struct Mma;
+template <>
+struct Mma<ffa_bf16> {
+  static __device__ __forceinline__ void run(const ffa_u32x4& a, const ffa_u32x4& b, ffa_f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ffa_bf16x8, a),
+                                                __builtin_bit_cast(ffa_bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <>
+struct Mma<float> {
+  static __device__ __forceinline__ void run(const ffa_u32x4& a, const ffa_u32x4& b, ffa_f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+template <int KH, int KW, int STRIDE, int RG, int BCO, int WCO, int WPX, int TH, int TW>
+struct ConvGeom {
+  static constexpr int NTHR = 64 * WCO * WPX;
+  static constexpr int NPX = TH * TW;
+  static constexpr int WAVE_CO = BCO / WCO;
+  static constexpr int MT = WAVE_CO / 32;
+  static constexpr int WAVE_PX = NPX / WPX;
+  static constexpr int NT = WAVE_PX / 32;
+  static constexpr bool ONE = (KH == 1 && KW == 1);
+  static constexpr int LS = ONE ? 1 : STRIDE;     // LDS pixel step between neighbouring outputs
+  static constexpr int GSTEP = ONE ? STRIDE : 1;  // global pixel step between neighbouring halo pixels
+  static constexpr int NRG = KH / RG;
+  static constexpr int IH = (TH - 1) * LS + RG;
+  static constexpr int IW = (TW - 1) * LS + KW;
+  static constexpr int PP = 48;
+  static constexpr int TAPS = RG * KW;
+  static constexpr int WP = TAPS * 32 + 16;
+  static constexpr int HALO_BYTES = IH * IW * PP;
+  static constexpr int W_BYTES = BCO * WP;
+  static constexpr int LDS_BYTES = HALO_BYTES + W_BYTES;
+  static constexpr int W_PIECES = BCO * TAPS * 2;
+  static constexpr int H_PIECES = IH * IW * 2;
+  static constexpr int NWP = (W_PIECES + NTHR - 1) / NTHR;
+  static constexpr int NHP = (H_PIECES + NTHR - 1) / NTHR;
+  static_assert(KH % RG == 0, "row group must divide kernel height");
+  static_assert(WAVE_CO == 32 || WAVE_CO == 64, "wave co tile");
+  static_assert(WAVE_PX % 32 == 0, "wave px tile");
+  static_assert((TW & (TW - 1)) == 0, "TW must be a power of two");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <typename T, int KH, int KW, int STRIDE, int RG, int BCO, int WCO, int WPX, int TH, int TW>
+__global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs a) {
+  using G = ConvGeom<KH, KW, STRIDE, RG, BCO, WCO, WPX, TH, TW>;
+  constexpr int EB = ElemTraits<T>::kBytes;
+  __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
+  unsigned char* sIn = smem;
+  unsigned char* sW = smem + G::HALO_BYTES;
+
+  // block -> (pixel tile, co block); blocks b and b+8 share an XCD (observed round-robin), so the
+  // co blocks of one pixel tile are kept on one XCD's L2 (speed only, never correctness)
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int j = bid >> 3;
+  const int pt = (j / a.ncb) * 8 + xcd;
+  const int cb = j % a.ncb;
+  if (pt >= a.npt) return;
+  const int tx = pt % a.tiles_x;
+  const int t2 = pt / a.tiles_x;
+  const int ty = t2 % a.tiles_y;
+  const int b = t2 / a.tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy_base = oy0 * STRIDE - a.pad;
+  const int ix_base = ox0 * STRIDE - a.pad;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wco = wave / WPX;
+  const int wpx = wave % WPX;
+  const int rho = lane & 31;
+  const int half = lane >> 5;
+
+  // per-lane LDS fragment offsets
+  int aoff[G::MT];
+#pragma unroll
+  for (int mt = 0; mt < G::MT; ++mt) {
+    int row;
+    if (G::MT == 2)
+      row = 16 * (rho >> 3) + 8 * ((rho >> 2) & 1) + 4 * mt + (rho & 3);
+    else
+      row = rho;
+    aoff[mt] = (wco * G::WAVE_CO + row) * G::WP + half * 16;
+  }
+  int boff[G::NT];
+#pragma unroll
+  for (int nt = 0; nt < G::NT; ++nt) {
+    const int n = wpx * G::WAVE_PX + nt * 32 + rho;
+    const int py = n / TW, px = n % TW;
+    boff[nt] = ((py * G::LS) * G::IW + px * G::LS) * G::PP + half * 16;
+  }
+
+  ffa_f32x16 acc[G::MT][G::NT];
+#pragma unroll
+  for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < G::NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const unsigned char* in_b = static_cast<const unsigned char*>(a.in);
+  const unsigned char* w_b = static_cast<const unsigned char*>(a.w) +
+                             (size_t)cb * a.nchunks * G::NRG * (size_t)(BCO * G::TAPS * 32);
+  const int total_chunks = a.nchunks * G::NRG;
+
+  ffa_u32x4 wreg[G::NWP];
+  ffa_u32x4 hreg[G::NHP];
+
+#define FFA_LOAD_CHUNK(c_)                                                                                   \
+  {                                                                                                          \
+    const int cc_ = (c_) / G::NRG;                                                                           \
+    const int rg_ = (c_) % G::NRG;                                                                           \
+    const ffa_u32x4* wsrc_ = reinterpret_cast<const ffa_u32x4*>(w_b + (size_t)(c_) * (BCO * G::TAPS * 32));         \
+    _Pragma("unroll") for (int k = 0; k < G::NWP; ++k) {                                                     \
+      const int i = tid + k * G::NTHR;                                                                       \
+      wreg[k] = wsrc_[(G::W_PIECES % G::NTHR == 0 || i < G::W_PIECES) ? i : 0];                              \
+    }                                                                                                        \
+    const int iy0_ = iy_base + rg_ * RG;                                                                     \
+    _Pragma("unroll") for (int k = 0; k < G::NHP; ++k) {                                                     \
+      const int i = tid + k * G::NTHR;                                                                       \
+      const int q = i >> 1;                                                                                  \
+      const int hh = i & 1;                                                                                  \
+      const int hy = q / G::IW, hx = q % G::IW;                                                              \
+      int vy = iy0_ + hy * G::GSTEP;                                                                         \
+      int vx = ix_base + hx * G::GSTEP;                                                                      \
+      bool ok = (i < G::H_PIECES) && vy >= 0 && vx >= 0;                                                     \
+      if (a.dil == 2) {                                                                                      \
+        ok = ok && (((vy | vx) & 1) == 0);                                                                   \
+        vy >>= 1;                                                                                            \
+        vx >>= 1;                                                                                            \
+      }                                                                                                      \
+      ok = ok && vy < a.Hi && vx < a.Wi;                                                                     \
+      ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};                                                                      \
+      if (ok) {                                                                                              \
+        const size_t off =                                                                                   \
+            ((size_t)(b * a.Hi + vy) * a.Wi + vx) * (size_t)(a.Ci * EB) + cc_ * 32 + hh * 16;                \
+        v = *reinterpret_cast<const ffa_u32x4*>(in_b + off);                                                     \
+      }                                                                                                      \
+      hreg[k] = v;                                                                                           \
+    }                                                                                                        \
+  }
+#define FFA_STORE_CHUNK()                                                                  \
+  {                                                                                        \
+    _Pragma("unroll") for (int k = 0; k < G::NWP; ++k) {                                   \
+      const int i = tid + k * G::NTHR;                                                     \
+      if (G::W_PIECES % G::NTHR == 0 || i < G::W_PIECES) {                                 \
+        const int row = i / (G::TAPS * 2), col = i % (G::TAPS * 2);                        \
+        *reinterpret_cast<ffa_u32x4*>(sW + row * G::WP + col * 16) = wreg[k];                  \
+      }                                                                                    \
+    }                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < G::NHP; ++k) {                                   \
+      const int i = tid + k * G::NTHR;                                                     \
+      if (G::H_PIECES % G::NTHR == 0 || i < G::H_PIECES)                                   \
+        *reinterpret_cast<ffa_u32x4*>(sIn + (i >> 1) * G::PP + (i & 1) * 16) = hreg[k];        \
+    }                                                                                      \
+  }
+
+  FFA_LOAD_CHUNK(0)
+  FFA_STORE_CHUNK()
+  __syncthreads();
+
+  for (int c = 0; c < total_chunks; ++c) {
+    const bool more = (c + 1 < total_chunks);
+    if (more) FFA_LOAD_CHUNK(c + 1)  // global loads stay in flight under the MFMAs below
+
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+#pragma unroll
+      for (int s = 0; s < KW; ++s) {
+        const int tap = r * KW + s;
+        ffa_u32x4 af[G::MT], bf[G::NT];
+#pragma unroll
+        for (int mt = 0; mt < G::MT; ++mt)
+          af[mt] = *reinterpret_cast<const ffa_u32x4*>(sW + aoff[mt] + tap * 32);
+#pragma unroll
+        for (int nt = 0; nt < G::NT; ++nt)
+          bf[nt] = *reinterpret_cast<const ffa_u32x4*>(sIn + boff[nt] + (r * G::IW + s) * G::PP);
+#pragma unroll
+        for (int mt = 0; mt < G::MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < G::NT; ++nt) Mma<T>::run(af[mt], bf[nt], acc[mt][nt]);
+      }
+    }
+    __syncthreads();
+    if (more) {
+      FFA_STORE_CHUNK()
+      __syncthreads();
+    }
+  }
+
+#undef FFA_LOAD_CHUNK
+#undef FFA_STORE_CHUNK
+
+  // epilogue: lane (rho, half) owns pixel n = wave px base + nt*32 + rho and, per g, a run of
+  // consecutive channels (8 for MT==2, 4 for MT==1)
+  T* out = static_cast<T*>(a.out);
+  const T* res = static_cast<const T*>(a.res);
+  const int co_wave = cb * BCO + wco * G::WAVE_CO;
+#pragma unroll
+  for (int nt = 0; nt < G::NT; ++nt) {
+    const int n = wpx * G::WAVE_PX + nt * 32 + rho;
+    const int oy = oy0 + n / TW, ox = ox0 + n % TW;
+    if (oy >= a.Ho || ox >= a.Wo) continue;
+    const size_t pix = ((size_t)(b * a.Ho + oy) * a.Wo + ox) * (size_t)a.Co;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (G::MT == 2) {
+        const int c0 = co_wave + 16 * g + 8 * half;
+        if (c0 >= a.Co) continue;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = acc[0][nt][4 * g + i];
+          v[4 + i] = acc[G::MT - 1][nt][4 * g + i];
+        }
+        if (a.bias) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] += a.bias[c0 + i];
+        }
+        if (res) {
+          float rv[8];
+          ffa_load8<T>(res + pix + c0, rv);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] += rv[i];
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        ffa_store8<T>(out + pix + c0, v);
+      } else {
+        const int c0 = co_wave + 8 * g + 4 * half;
+        if (c0 >= a.Co) continue;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[0][nt][4 * g + i];
+        if (a.bias) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += a.bias[c0 + i];
+        }
+        if (res) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += ffa_load_elem<T>(res + pix + c0 + i);
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        if (EB == 2) {
+          uint2 u;
+          u.x = ffa_pack_bf16x2(v[0], v[1]);
+          u.y = ffa_pack_bf16x2(v[2], v[3]);
+          *reinterpret_cast<uint2*>(out + pix + c0) = u;
+        } else {
+          *reinterpret_cast<float4*>(out + pix + c0) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: configuration choice + launch
+
+struct ConvPlan {
+  int bco;     // output channels per block (= row count of one packed weight slab)
+  int rg;      // kernel rows per chunk
+  int th, tw;  // output pixel tile
+};
+
+static int conv_rg(int kh) { return kh == 7 ? 1 : kh; }
+
+// Preferred block height in output channels for a layer with `cout` real output channels.  The
+// caller packs the weights with this value and hands the same value back to ffa_conv2d.
+static int conv_pref_bco(int kh, int kw, int stride, int cout) {
+  if (kh == 3 && kw == 3 && stride == 1) return cout > 64 ? 128 : (cout > 32 ? 64 : 32);
+  return cout > 32 ? 64 : 32;
+}
+
+static bool conv_supported(int kh, int kw, int stride, int bco) {
+  const bool shape = (kh == 3 && kw == 3 && (stride == 1 || stride == 2)) ||
+                     (kh == 1 && kw == 1 && (stride == 1 || stride == 2)) || (kh == 7 && kw == 7 && stride == 2);
+  if (!shape) return false;
+  if (bco == 128) return kh == 3 && stride == 1;
+  return bco == 64 || bco == 32;
+}
+
+template <typename T, int KH, int KW, int STRIDE, int RG, int BCO, int WCO, int WPX, int TH, int TW>
+static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
+  const int grid = ffa_cdiv(a.npt, 8) * 8 * a.ncb;
+  hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, STRIDE, RG, BCO, WCO, WPX, TH, TW>), dim3(grid),
+                     dim3(64 * WCO * WPX), 0, stream, a);
+  return ffa_check_launch("conv_igemm");
+}
+
+template <typename T, int KH, int KW, int STRIDE, int RG>
+static int launch_shape(const ConvArgs& a, const ConvPlan& p, hipStream_t stream) {
+  const bool wide = (p.tw == 32);
+#define FFA_CONV_CASE(BCO_, WCO_, WPX_)                                                      \
+  if (p.bco == BCO_) {                                                                       \
+    return wide ? launch_cfg<T, KH, KW, STRIDE, RG, BCO_, WCO_, WPX_, 8, 32>(a, stream)      \
+                : launch_cfg<T, KH, KW, STRIDE, RG, BCO_, WCO_, WPX_, 16, 16>(a, stream);    \
+  }
+  if constexpr (KH == 3 && STRIDE == 1) {
+    FFA_CONV_CASE(128, 2, 2)
+  }
+  FFA_CONV_CASE(64, 1, 4)
+  FFA_CONV_CASE(32, 1, 4)
+#undef FFA_CONV_CASE
+  ffa_set_error("conv: no kernel for bco=%d", p.bco);
+  return FFA_ERR_UNSUPPORTED;
+}
+
+template <typename T>
+static int launch_dtype(const ConvArgs& a, int kh, int kw, int stride, const ConvPlan& p, hipStream_t stream) {
+  if (kh == 3 && kw == 3 && stride == 1) return launch_shape<T, 3, 3, 1, 3>(a, p, stream);
+  if (kh == 3 && kw == 3 && stride == 2) return launch_shape<T, 3, 3, 2, 3>(a, p, stream);
+  if (kh == 1 && kw == 1 && stride == 1) return launch_shape<T, 1, 1, 1, 1>(a, p, stream);
+  if (kh == 1 && kw == 1 && stride == 2) return launch_shape<T, 1, 1, 2, 1>(a, p, stream);
+  if (kh == 7 && kw == 7 && stride == 2) return launch_shape<T, 7, 7, 2, 1>(a, p, stream);
+  ffa_set_error("conv: unsupported kernel %dx%d stride %d", kh, kw, stride);
+  return FFA_ERR_UNSUPPORTED;
+}
+
+extern "C" int ffa_conv_block_co(int kh, int kw, int stride, int cout) {
+  const int bco = conv_pref_bco(kh, kw, stride, cout);
+  return conv_supported(kh, kw, stride, bco) ? bco : FFA_ERR_UNSUPPORTED;
+}
+
+extern "C" int ffa_conv_row_group(int kh) { return conv_rg(kh); }
+
+extern "C" int ffa_conv2d(int dtype, const void* in, const void* w_packed, const float* bias, const void* residual,
+                          void* out, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int co_rows, int bco,
+                          int kh, int kw, int stride, int pad, int dil, int relu, hipStream_t stream) {
+  FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "conv: bad dtype %d", dtype);
+  FFA_REQUIRE(in && w_packed && out, "conv: null pointer");
+  FFA_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "conv: bad dims");
+  FFA_REQUIRE(Ci % 16 == 0 && Co % 8 == 0, "conv: channel pitch must be a multiple of 16 (in) / 8 (out), got %d/%d", Ci, Co);
+  FFA_REQUIRE(dil == 1 || dil == 2, "conv: dil must be 1 or 2");
+  FFA_REQUIRE(dil == 1 || stride == 1, "conv: zero-insertion input needs stride 1");
+  if (!conv_supported(kh, kw, stride, bco)) {
+    ffa_set_error("conv: unsupported kernel %dx%d stride %d block %d", kh, kw, stride, bco);
+    return FFA_ERR_UNSUPPORTED;
+  }
+  ConvPlan p;
+  p.bco = bco;
+  p.rg = conv_rg(kh);
+  p.tw = (Wo >= 32) ? 32 : 16;
+  p.th = (Wo >= 32) ? 8 : 16;
+  FFA_REQUIRE(co_rows % p.bco == 0, "conv: packed weight rows %d not a multiple of block %d", co_rows, p.bco);
+  ConvArgs a;
+  a.in = in;
+  a.w = w_packed;
+  a.out = out;
+  a.bias = bias;
+  a.res = residual;
+  a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci;
+  a.Ho = Ho; a.Wo = Wo; a.Co = Co;
+  a.pad = pad; a.dil = dil; a.relu = relu;
+  const int eb = (dtype == FFA_BF16) ? 2 : 4;
+  a.nchunks = Ci * eb / 32;
+  a.tiles_x = ffa_cdiv(Wo, p.tw);
+  a.tiles_y = ffa_cdiv(Ho, p.th);
+  a.npt = B * a.tiles_x * a.tiles_y;
+  a.ncb = co_rows / p.bco;
+  if (dtype == FFA_BF16) return launch_dtype<ffa_bf16>(a, kh, kw, stride, p, stream);
+  return launch_dtype<float>(a, kh, kw, stride, p, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: OIHW f32 master weights -> per-(co block, chunk, row group) LDS-image slabs
+//   dst[cb][cc][rg][row < BCO][tap < RG*KW][e < 32/sizeof(T)]
+// src element (row, ch, r, s) is read at src[row*s_row + ch*s_ch + r*KW + s]; flip mirrors the taps
+// (dgrad: rows = ci, ch = co, flipped).  scale[row] (optional) folds an eval-mode BN into the weights.
+
+struct PackArgs {
+  const float* src;
+  void* dst;
+  const float* scale;
+  long long s_row, s_ch;
+  int rows, chs;  // valid rows / channels in src
+  int kh, kw, rg, bco, nchunks, ncb, flip;
+};
+
+template <typename T>
+__global__ void pack_weight_kernel(PackArgs p) {
+  constexpr int EPC = ElemTraits<T>::kPerStep;
+  const int taps = p.rg * p.kw;
+  const int nrg = p.kh / p.rg;
+  const long long total = (long long)p.ncb * p.nchunks * nrg * p.bco * taps * EPC;
+  T* dst = static_cast<T*>(p.dst);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long t = i;
+    const int e = t % EPC; t /= EPC;
+    const int tap = t % taps; t /= taps;
+    const int row_l = t % p.bco; t /= p.bco;
+    const int rg = t % nrg; t /= nrg;
+    const int cc = t % p.nchunks; t /= p.nchunks;
+    const int cb = (int)t;
+    const int row = cb * p.bco + row_l;
+    const int ch = cc * EPC + e;
+    int r = rg * p.rg + tap / p.kw;
+    int s = tap % p.kw;
+    float v = 0.f;
+    if (row < p.rows && ch < p.chs) {
+      if (p.flip) {
+        r = p.kh - 1 - r;
+        s = p.kw - 1 - s;
+      }
+      v = p.src[row * p.s_row + ch * p.s_ch + r * p.kw + s];
+      if (p.scale) v *= p.scale[row];
+    }
+    ffa_store_elem<T>(dst + i, v);
+  }
+}
+
+extern "C" long long ffa_pack_conv_weight_bytes(int dtype, int co_rows, int ci_pitch, int kh, int kw) {
+  const long long eb = (dtype == FFA_BF16) ? 2 : 4;
+  return (long long)co_rows * ci_pitch * kh * kw * eb;
+}
+
+// co_rows / ci_pitch: padded row count (multiple of the block size from ffa_conv_block_co) and the
+// channel pitch of the activation the conv will read.  transpose=1 builds the dgrad operand from the
+// same OIHW tensor (rows = input channels, channels = output channels, taps mirrored).
+extern "C" int ffa_pack_conv_weight(int dtype, const float* w_oihw, const float* scale, void* dst, int O, int I,
+                                    int kh, int kw, int transpose, int co_rows, int ci_pitch, int bco, int rg,
+                                    hipStream_t stream) {
+  FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "pack: bad dtype");
+  FFA_REQUIRE(w_oihw && dst, "pack: null pointer");
+  FFA_REQUIRE(bco > 0 && co_rows % bco == 0, "pack: rows %d not a multiple of block %d", co_rows, bco);
+  FFA_REQUIRE(rg > 0 && kh % rg == 0, "pack: bad row group");
+  const int epc = (dtype == FFA_BF16) ? 16 : 8;
+  FFA_REQUIRE(ci_pitch % 16 == 0, "pack: channel pitch must be a multiple of 16");
+  PackArgs p;
+  p.src = w_oihw;
+  p.dst = dst;
+  p.scale = scale;
+  if (!transpose) {
+    p.rows = O; p.chs = I;
+    p.s_row = (long long)I * kh * kw;
+    p.s_ch = (long long)kh * kw;
+    p.flip = 0;
+  } else {
+    p.rows = I; p.chs = O;
+    p.s_row = (long long)kh * kw;
+    p.s_ch = (long long)I * kh * kw;
+    p.flip = 1;
+  }
+  FFA_REQUIRE(p.rows <= co_rows && p.chs <= ci_pitch, "pack: padded dims smaller than the tensor");
+  p.kh = kh; p.kw = kw; p.rg = rg; p.bco = bco;
+  p.nchunks = ci_pitch / epc;
+  p.ncb = co_rows / bco;
+  const long long total = (long long)co_rows * ci_pitch * kh * kw;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(pack_weight_kernel<ffa_bf16>, dim3(grid), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, stream, p);
+  return ffa_check_launch("pack_weight");
+}

@@ -1,0 +1,417 @@
+// Weight gradient of the NHWC convolutions on MFMA (gfx950).
+//
+//   dW[co][r][s][ci] = sum over (b, oy, ox) of dy[b][oy][ox][co] * x[b][oy*st - pad + r][ox*st - pad + s][ci]
+//
+// (the backward of the conv2d calls named in conv_igemm.hip).  GEMM view: M = co, N = ci, one
+// accumulator tile per tap, K = output pixels.  Both operands have K (pixels) as their slow memory
+// axis in NHWC, so the tiles are staged in natural [pixel][32 channels] form and the K-contiguous
+// MFMA fragments are produced by the LDS transpose read ds_read_b64_tr_b16 (bf16) or by plain
+// ds_read_b32 (f32: one element per lane per v_mfma_f32_32x32x2_f32).  Because the tr read takes a
+// per-lane row address, the 9 tap shifts of the input halo cost nothing: one halo tile in LDS
+// serves all taps.
+//
+// Work split: block = (co block, ci block, kernel-row group) x split; a split walks a strided
+// subset of the spatial tiles and writes its f32 partial slab; wgrad_reduce_kernel sums the
+// slabs in fixed order (deterministic, no float atomics) and writes the OIHW f32 gradient.
+#include "ffa_common.h"
+
+struct WgradArgs {
+  const void* x;
+  const void* dy;
+  float* slabs;  // [nsplit][CoT][KH*KW][CiT]
+  int B, Hi, Wi, Ci;
+  int Ho, Wo, Co;
+  int pad;
+  int tiles_x, tiles_y, npt;
+  int ncob, ncib, nsplit;
+  int CoT, CiT;
+};
+
+template <int KH, int KW, int STRIDE, int RG, int WCO, int WCI, int TH, int TW, int EB>
+struct WgradGeom {
+  static constexpr int NTHR = 64 * WCO * WCI;
+  static constexpr int NPX = TH * TW;
+  static constexpr bool ONE = (KH == 1 && KW == 1);
+  static constexpr int LS = ONE ? 1 : STRIDE;
+  static constexpr int GSTEP = ONE ? STRIDE : 1;
+  static constexpr int NRG = KH / RG;
+  static constexpr int IH = (TH - 1) * LS + RG;
+  static constexpr int IW = (TW - 1) * LS + KW;
+  static constexpr int TAPS = RG * KW;
+  static constexpr int ROWB = 32 * EB;         // bytes of one pixel row of a 32-channel plane
+  static constexpr int PARTS = ROWB / 16;      // 16-byte pieces per pixel row
+  static constexpr int DY_BYTES = WCO * NPX * ROWB;
+  static constexpr int IN_BYTES = WCI * IH * IW * ROWB;
+  static constexpr int LDS_BYTES = DY_BYTES + IN_BYTES;
+  static constexpr int DY_PIECES = WCO * NPX * PARTS;
+  static constexpr int IN_PIECES = WCI * IH * IW * PARTS;
+  static constexpr int NDP = (DY_PIECES + NTHR - 1) / NTHR;
+  static constexpr int NIP = (IN_PIECES + NTHR - 1) / NTHR;
+  static_assert(TW % 16 == 0, "a 16-pixel k-step must stay inside one tile row");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// 4 pixels x 16 channels of bf16, transposed: lane (16-lane group member li) passes the address of
+// pixel row (li >> 2), 8-byte segment (li & 3); it receives channel li of the four pixels.
+__device__ __forceinline__ ffa_s16x4 lds_read_tr16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) ffa_s16x4*)(const_cast<unsigned char*>(p)));
+}
+
+template <typename T, int KH, int KW, int STRIDE, int RG, int WCO, int WCI, int TH, int TW>
+__global__ void __launch_bounds__(64 * WCO * WCI) conv_wgrad_kernel(WgradArgs a) {
+  constexpr int EB = ElemTraits<T>::kBytes;
+  using G = WgradGeom<KH, KW, STRIDE, RG, WCO, WCI, TH, TW, EB>;
+  __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
+  unsigned char* sDy = smem;
+  unsigned char* sIn = smem + G::DY_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wco = wave / WCI, wci = wave % WCI;
+
+  int tb = blockIdx.x;
+  const int rg = tb % G::NRG;
+  tb /= G::NRG;
+  const int cib = tb % a.ncib;
+  const int cob = tb / a.ncib;
+  const int split = blockIdx.y;
+  const int co0 = cob * 32 * WCO;  // first output channel of the block
+  const int ci0 = cib * 32 * WCI;
+
+  ffa_f32x16 acc[G::TAPS];
+#pragma unroll
+  for (int t = 0; t < G::TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const unsigned char* x_b = static_cast<const unsigned char*>(a.x);
+  const unsigned char* dy_b = static_cast<const unsigned char*>(a.dy);
+
+  // fragment addressing (see file header)
+  const int li = lane & 15;
+  const int gsel = (lane >> 4) & 1;
+  const int khalf = lane >> 5;
+  const unsigned char* dyPlane = sDy + wco * (G::NPX * G::ROWB);
+  const unsigned char* inPlane = sIn + wci * (G::IH * G::IW * G::ROWB);
+
+  for (int pt = split; pt < a.npt; pt += a.nsplit) {
+    const int tx = pt % a.tiles_x;
+    const int t2 = pt / a.tiles_x;
+    const int ty = t2 % a.tiles_y;
+    const int b = t2 / a.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * STRIDE - a.pad + rg * RG;
+    const int ix0 = ox0 * STRIDE - a.pad;
+
+    __syncthreads();  // previous tile's fragment reads are done
+    // ---- stage dy tile: [plane][pixel][32 ch]
+#pragma unroll 4
+    for (int k = 0; k < G::NDP; ++k) {
+      const int i = tid + k * G::NTHR;
+      if (i < G::DY_PIECES) {
+        const int part = i % G::PARTS;
+        const int n = (i / G::PARTS) % G::NPX;
+        const int plane = i / (G::PARTS * G::NPX);
+        const int oy = oy0 + n / TW, ox = ox0 + n % TW;
+        const int c = co0 + plane * 32 + part * (16 / EB);
+        ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};
+        if (oy < a.Ho && ox < a.Wo && c < a.Co)
+          v = *reinterpret_cast<const ffa_u32x4*>(dy_b + (((size_t)(b * a.Ho + oy) * a.Wo + ox) * a.Co + c) * EB);
+        *reinterpret_cast<ffa_u32x4*>(sDy + (plane * G::NPX + n) * G::ROWB + part * 16) = v;
+      }
+    }
+    // ---- stage input halo: [plane][halo pixel][32 ch]
+#pragma unroll 4
+    for (int k = 0; k < G::NIP; ++k) {
+      const int i = tid + k * G::NTHR;
+      if (i < G::IN_PIECES) {
+        const int part = i % G::PARTS;
+        const int q = (i / G::PARTS) % (G::IH * G::IW);
+        const int plane = i / (G::PARTS * G::IH * G::IW);
+        const int vy = iy0 + (q / G::IW) * G::GSTEP;
+        const int vx = ix0 + (q % G::IW) * G::GSTEP;
+        const int c = ci0 + plane * 32 + part * (16 / EB);
+        ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};
+        if (vy >= 0 && vx >= 0 && vy < a.Hi && vx < a.Wi && c < a.Ci)
+          v = *reinterpret_cast<const ffa_u32x4*>(x_b + (((size_t)(b * a.Hi + vy) * a.Wi + vx) * a.Ci + c) * EB);
+        *reinterpret_cast<ffa_u32x4*>(sIn + (plane * (G::IH * G::IW) + q) * G::ROWB + part * 16) = v;
+      }
+    }
+    __syncthreads();
+
+    // ---- K loop over the tile's pixels, 16 per step
+#pragma unroll 1
+    for (int ks = 0; ks < G::NPX / 16; ++ks) {
+      const int n0 = ks * 16;
+      const int py = n0 / TW, px0 = n0 % TW;
+      if constexpr (EB == 2) {
+        // A fragment: co = lane & 31, k = 8*khalf + j
+        const int pa = n0 + 8 * khalf + (li >> 2);
+        const unsigned char* ap = dyPlane + pa * G::ROWB + gsel * 32 + (li & 3) * 8;
+        const ffa_s16x4 a0 = lds_read_tr16(ap);
+        const ffa_s16x4 a1 = lds_read_tr16(ap + 4 * G::ROWB);
+        ffa_u32x4 af;
+        af.x = __builtin_bit_cast(ffa_u32x2, a0).x;
+        af.y = __builtin_bit_cast(ffa_u32x2, a0).y;
+        af.z = __builtin_bit_cast(ffa_u32x2, a1).x;
+        af.w = __builtin_bit_cast(ffa_u32x2, a1).y;
+        const int pxl = px0 + 8 * khalf + (li >> 2);
+        const unsigned char* bbase =
+            inPlane + ((py * G::LS) * G::IW + pxl * G::LS) * G::ROWB + gsel * 32 + (li & 3) * 8;
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+          for (int s = 0; s < KW; ++s) {
+            const unsigned char* bp = bbase + (r * G::IW + s) * G::ROWB;
+            const ffa_s16x4 b0 = lds_read_tr16(bp);
+            const ffa_s16x4 b1 = lds_read_tr16(bp + 4 * G::LS * G::ROWB);
+            ffa_u32x4 bf;
+            bf.x = __builtin_bit_cast(ffa_u32x2, b0).x;
+            bf.y = __builtin_bit_cast(ffa_u32x2, b0).y;
+            bf.z = __builtin_bit_cast(ffa_u32x2, b1).x;
+            bf.w = __builtin_bit_cast(ffa_u32x2, b1).y;
+            acc[r * KW + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(ffa_bf16x8, af), __builtin_bit_cast(ffa_bf16x8, bf), acc[r * KW + s], 0, 0, 0);
+          }
+      } else {
+        // f32: 8 MFMAs of k = 2 pixels; lane supplies A[co = lane&31][k = lane>>5], B[k][ci = lane&31]
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const int n = n0 + 2 * m + khalf;
+          const float av = *reinterpret_cast<const float*>(dyPlane + n * G::ROWB + (lane & 31) * 4);
+          const int pxl = px0 + 2 * m + khalf;
+          const unsigned char* bbase = inPlane + ((py * G::LS) * G::IW + pxl * G::LS) * G::ROWB + (lane & 31) * 4;
+#pragma unroll
+          for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int s = 0; s < KW; ++s) {
+              const float bv = *reinterpret_cast<const float*>(bbase + (r * G::IW + s) * G::ROWB);
+              acc[r * KW + s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[r * KW + s], 0, 0, 0);
+            }
+        }
+      }
+    }
+  }
+
+  // ---- write the partial slab: D[co][ci], lane column = ci, rows co = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int ci = ci0 + wci * 32 + (lane & 31);
+  const int co_w = co0 + wco * 32;
+  const size_t taps_total = (size_t)KH * KW;
+#pragma unroll
+  for (int t = 0; t < G::TAPS; ++t) {
+    const int tapg = rg * G::TAPS + t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co_w + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      a.slabs[(((size_t)split * a.CoT + co) * taps_total + tapg) * a.CiT + ci] = acc[t][r];
+    }
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int nsplit, int CoT,
+                                    int CiT, int Co, int Ci, int taps, int accumulate) {
+  // dw is OIHW [Co][Ci][taps]; consecutive threads take consecutive ci of one (co, tap) so the slab
+  // reads are coalesced
+  const long long total = (long long)Co * taps * Ci;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Ci);
+    const long long t2 = i / Ci;
+    const int tap = (int)(t2 % taps);
+    const int co = (int)(t2 / taps);
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slabs[(((size_t)k * CoT + co) * taps + tap) * CiT + ci];
+    float* dst = dw + ((size_t)co * Ci + ci) * taps + tap;
+    *dst = accumulate ? (*dst + s) : s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+
+struct WgradPlan {
+  int wco, wci, th, tw, rg, nsplit, ncob, ncib, CoT, CiT, npt, tiles_x, tiles_y;
+};
+
+static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, int B, int Ho, int Wo, WgradPlan* p) {
+  const bool s1 = (kh == 3 && kw == 3 && stride == 1);
+  const bool s2 = (kh == 3 && kw == 3 && stride == 2);
+  const bool one = (kh == 1 && kw == 1 && (stride == 1 || stride == 2));
+  const bool stem = (kh == 7 && kw == 7 && stride == 2);
+  if (!(s1 || s2 || one || stem)) return false;
+  p->rg = stem ? 1 : kh;
+  p->tw = (Wo >= 32) ? 32 : 16;
+  p->th = (Wo >= 32) ? 8 : 16;
+  if (s2 || stem) {  // halo of a stride-2 tile is 4x larger: halve the tile
+    p->tw = 16;
+    p->th = 8;
+  }
+  p->wco = (Co > 32) ? 2 : 1;
+  p->wci = (Ci > 32) ? 2 : 1;
+  if (dtype == FFA_F32) p->wci = 1;  // f32 planes are twice as large; keep LDS under 160 KiB
+  if (!s1) {                         // only the shapes the network needs are instantiated
+    p->wco = 2;
+    p->wci = (dtype == FFA_F32 || stem) ? 1 : 2;
+  }
+  p->ncob = ffa_cdiv(Co, 32 * p->wco);
+  p->ncib = ffa_cdiv(Ci, 32 * p->wci);
+  p->CoT = p->ncob * 32 * p->wco;
+  p->CiT = p->ncib * 32 * p->wci;
+  p->tiles_x = ffa_cdiv(Wo, p->tw);
+  p->tiles_y = ffa_cdiv(Ho, p->th);
+  p->npt = B * p->tiles_x * p->tiles_y;
+  const int tile_blocks = p->ncob * p->ncib * (kh / p->rg);
+  int ns = ffa_cdiv(768, tile_blocks);
+  if (ns > p->npt) ns = p->npt;
+  if (ns < 1) ns = 1;
+  p->nsplit = ns;
+  return true;
+}
+
+extern "C" long long ffa_conv_wgrad_workspace_bytes(int dtype, int kh, int kw, int stride, int Co, int Ci, int B, int Ho,
+                                                    int Wo) {
+  WgradPlan p;
+  if (!wgrad_plan(dtype, kh, kw, stride, Co, Ci, B, Ho, Wo, &p)) return FFA_ERR_UNSUPPORTED;
+  return (long long)p.nsplit * p.CoT * kh * kw * p.CiT * (long long)sizeof(float);
+}
+
+template <typename T, int KH, int KW, int STRIDE, int RG, int WCO, int WCI, int TH, int TW>
+static void launch_wgrad_cfg(const WgradArgs& a, int nrg, hipStream_t stream) {
+  dim3 grid(a.ncob * a.ncib * nrg, a.nsplit);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW, STRIDE, RG, WCO, WCI, TH, TW>), grid, dim3(64 * WCO * WCI), 0,
+                     stream, a);
+}
+
+template <typename T>
+static int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int kh, int kw, int stride, hipStream_t stream) {
+  constexpr bool F32 = (sizeof(T) == 4);
+  const bool wide = (p.tw == 32);
+  if (kh == 3 && stride == 1) {
+#define FFA_WG_S1(WCO_, WCI_)                                                        \
+  if (p.wco == WCO_ && p.wci == WCI_) {                                              \
+    if (wide) launch_wgrad_cfg<T, 3, 3, 1, 3, WCO_, WCI_, 8, 32>(a, 1, stream);      \
+    else launch_wgrad_cfg<T, 3, 3, 1, 3, WCO_, WCI_, 16, 16>(a, 1, stream);          \
+    return ffa_check_launch("conv_wgrad");                                           \
+  }
+    FFA_WG_S1(2, 1)
+    FFA_WG_S1(1, 1)
+    if constexpr (!F32) {
+      FFA_WG_S1(2, 2)
+      FFA_WG_S1(1, 2)
+    }
+#undef FFA_WG_S1
+  } else if (kh == 3 && stride == 2) {
+    launch_wgrad_cfg<T, 3, 3, 2, 3, 2, F32 ? 1 : 2, 8, 16>(a, 1, stream);
+    return ffa_check_launch("conv_wgrad");
+  } else if (kh == 1 && stride == 2) {
+    launch_wgrad_cfg<T, 1, 1, 2, 1, 2, F32 ? 1 : 2, 8, 16>(a, 1, stream);
+    return ffa_check_launch("conv_wgrad");
+  } else if (kh == 1 && stride == 1) {
+    launch_wgrad_cfg<T, 1, 1, 1, 1, 2, F32 ? 1 : 2, 8, 16>(a, 1, stream);
+    return ffa_check_launch("conv_wgrad");
+  } else if (kh == 7) {
+    launch_wgrad_cfg<T, 7, 7, 2, 1, 2, 1, 8, 16>(a, 7, stream);
+    return ffa_check_launch("conv_wgrad");
+  }
+  ffa_set_error("conv_wgrad: no kernel for %dx%d stride %d waves %dx%d", kh, kw, stride, p.wco, p.wci);
+  return FFA_ERR_UNSUPPORTED;
+}
+
+// x: [B][Hi][Wi][Ci] (the conv input), dy: [B][Ho][Wo][Co]; Ci / Co are channel pitches, the
+// gradient is written for the first Co_real x Ci_real entries as OIHW f32 (accumulate != 0 adds to it).
+extern "C" int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int B, int Hi, int Wi, int Ci,
+                              int Ho, int Wo, int Co, int Co_real, int Ci_real, int kh, int kw, int stride, int pad,
+                              int accumulate, void* workspace, long long workspace_bytes, hipStream_t stream) {
+  FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "conv_wgrad: bad dtype");
+  FFA_REQUIRE(x && dy && dw_oihw && workspace, "conv_wgrad: null pointer");
+  FFA_REQUIRE(Ci % 8 == 0 && Co % 8 == 0, "conv_wgrad: channel pitch must be a multiple of 8");
+  FFA_REQUIRE(Co_real <= Co && Ci_real <= Ci, "conv_wgrad: real channels exceed pitch");
+  WgradPlan p;
+  if (!wgrad_plan(dtype, kh, kw, stride, Co, Ci, B, Ho, Wo, &p)) {
+    ffa_set_error("conv_wgrad: unsupported kernel %dx%d stride %d", kh, kw, stride);
+    return FFA_ERR_UNSUPPORTED;
+  }
+  const long long need = (long long)p.nsplit * p.CoT * kh * kw * p.CiT * (long long)sizeof(float);
+  if (workspace_bytes < need) {
+    ffa_set_error("conv_wgrad: workspace too small (%lld < %lld)", workspace_bytes, need);
+    return FFA_ERR_WORKSPACE;
+  }
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.slabs = static_cast<float*>(workspace);
+  a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci;
+  a.Ho = Ho; a.Wo = Wo; a.Co = Co;
+  a.pad = pad;
+  a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.npt = p.npt;
+  a.ncob = p.ncob; a.ncib = p.ncib; a.nsplit = p.nsplit;
+  a.CoT = p.CoT; a.CiT = p.CiT;
+  int rc = (dtype == FFA_BF16) ? launch_wgrad<ffa_bf16>(a, p, kh, kw, stride, stream)
+                               : launch_wgrad<float>(a, p, kh, kw, stride, stream);
+  if (rc != FFA_OK) return rc;
+  const long long total = (long long)Co_real * kh * kw * Ci_real;
+  long long g = (total + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)g), dim3(256), 0, stream, (const float*)workspace, dw_oihw,
+                     p.nsplit, p.CoT, p.CiT, Co_real, Ci_real, kh * kw, accumulate);
+  return ffa_check_launch("wgrad_reduce");
+}
+
+// ------------------------------------------------------------------------------------------------
+// hardware-layout probes used by tests/test_layout_probes.py: they pin the lane maps this file and
+// conv_igemm.hip rely on (MFMA operand / accumulator layout, transpose-read semantics).
+
+__global__ void probe_tr16_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst) {
+  // src: 64 rows x 64 bf16 (128-B rows).  Each lane reads with row = lane>>2 .. as documented above
+  __shared__ __align__(16) unsigned char buf[64 * 128];
+  for (int i = threadIdx.x; i < 64 * 64; i += 64) reinterpret_cast<uint16_t*>(buf)[i] = src[i];
+  __syncthreads();
+  const int lane = threadIdx.x;
+  const int li = lane & 15;
+  const int grp = lane >> 4;
+  // group g reads rows 4g..4g+3, columns 16g.. : address of row (li>>2), segment (li&3)
+  const unsigned char* p = buf + (4 * grp + (li >> 2)) * 128 + grp * 32 + (li & 3) * 8;
+  ffa_s16x4 v = lds_read_tr16(p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) dst[lane * 4 + e] = (uint16_t)v[e];
+}
+
+extern "C" int ffa_probe_tr16(const uint16_t* src, uint16_t* dst, hipStream_t stream) {
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, stream, src, dst);
+  return ffa_check_launch("probe_tr16");
+}
+
+__global__ void probe_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ D,
+                                  int use_f32) {
+  // A: [32][16] row-major, B: [16][32] row-major, D: [32][32] row-major, values exactly representable in bf16
+  const int lane = threadIdx.x;
+  const int rho = lane & 31, half = lane >> 5;
+  ffa_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (!use_f32) {
+    ffa_bf16x8 a, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a[j] = (__bf16)A[rho * 16 + 8 * half + j];
+      b[j] = (__bf16)Bm[(8 * half + j) * 32 + rho];
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // same lane->k map as the bf16 path at 16-byte granularity: k = 4*half + j, second k block +8
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rho * 16 + 4 * half + j], Bm[(4 * half + j) * 32 + rho], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rho * 16 + 8 + 4 * half + j], Bm[(8 + 4 * half + j) * 32 + rho], acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+    D[row * 32 + rho] = acc[r];
+  }
+}
+
+extern "C" int ffa_probe_mfma(const float* A, const float* B, float* D, int use_f32, hipStream_t stream) {
+  hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, stream, A, B, D, use_f32);
+  return ffa_check_launch("probe_mfma");
+}

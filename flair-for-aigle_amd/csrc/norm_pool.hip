@@ -1,0 +1,496 @@
+// BatchNorm2d (train / eval, forward + backward), MaxPool2d 3x3 s2 p1 (forward + backward) and the
+// NCHW f32 <-> NHWC layout hand-over, all NHWC, bf16 or f32 storage with f32 arithmetic.
+//
+// These replace the ATen batch_norm / relu / max_pool2d calls that segmentation_models_pytorch's
+// ResNet-34 encoder and UnetDecoder make (reached from flair_hub/models/flair_model.py:376 and
+// :417-419; BN eps 1e-5, momentum 0.1).  All are HBM-bound: every thread moves
+// 8 consecutive channels (16 B of bf16) per access, per-channel reductions are two-stage
+// (per-block partials in a caller workspace, then a fixed-order finalize) so results are
+// bitwise reproducible run to run -- no float atomics.
+#include "ffa_common.h"
+
+#define FFA_EW_THREADS 256
+#define FFA_MAX_PARTIALS 1024
+
+static inline int ew_grid(long long items) {
+  long long g = (items + FFA_EW_THREADS - 1) / FFA_EW_THREADS;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout hand-over at the model boundary
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C, int H, int W,
+                                    int Cp) {
+  // one thread per (pixel, 8-channel group): reads are coalesced along x within each plane
+  const int groups = Cp / 8;
+  const long long total = (long long)B * H * W * groups;
+  const long long hw = (long long)H * W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    // pixel fastest so that neighbouring threads read neighbouring x of one plane
+    const long long pix = i % ((long long)B * hw);
+    const int g = (int)(i / ((long long)B * hw));
+    const long long b = pix / hw, p = pix % hw;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = g * 8 + e;
+      v[e] = (c < C) ? src[(b * C + c) * hw + p] : 0.f;
+    }
+    ffa_store8<T>(dst + pix * Cp + g * 8, v);
+  }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int C, int H, int W,
+                                    int Cp) {
+  const long long hw = (long long)H * W;
+  const long long total = (long long)B * C * hw;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i % hw;
+    const long long bc = i / hw;
+    const int c = (int)(bc % C);
+    const long long b = bc / C;
+    dst[i] = ffa_load_elem<T>(src + (b * hw + p) * Cp + c);
+  }
+}
+
+extern "C" int ffa_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H, int W, int Cp,
+                                hipStream_t stream) {
+  FFA_REQUIRE(src && dst && Cp % 8 == 0 && Cp >= C, "nchw_to_nhwc: bad arguments (C=%d Cp=%d)", C, Cp);
+  const long long items = (long long)B * H * W * (Cp / 8);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<ffa_bf16>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream, src,
+                       (ffa_bf16*)dst, B, C, H, W, Cp);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream, src,
+                       (float*)dst, B, C, H, W, Cp);
+  return ffa_check_launch("nchw_to_nhwc");
+}
+
+extern "C" int ffa_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H, int W, int Cp,
+                                hipStream_t stream) {
+  FFA_REQUIRE(src && dst && Cp >= C, "nhwc_to_nchw: bad arguments");
+  const long long items = (long long)B * C * H * W;
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<ffa_bf16>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const ffa_bf16*)src, dst, B, C, H, W, Cp);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const float*)src, dst, B, C, H, W, Cp);
+  return ffa_check_launch("nhwc_to_nchw");
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-channel two-value reductions over [N pixels][C]:  thread t owns channel group t % CG and
+// pixel lane t / CG; block partials land in ws[block][2][C]
+
+struct StatOp {  // sum(x), sum(x^2)
+  template <typename T>
+  __device__ __forceinline__ void operator()(long long off, float (&a)[8], float (&b)[8], const T* x, const T*,
+                                             const T*, const float*, const float*, int, int) const {
+    float v[8];
+    ffa_load8<T>(x + off, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a[e] += v[e];
+      b[e] += v[e] * v[e];
+    }
+  }
+};
+
+struct BnBwdOp {  // sum(g), sum(g * xhat) with g = dy * (y > 0 if relu)
+  template <typename T>
+  __device__ __forceinline__ void operator()(long long off, float (&a)[8], float (&b)[8], const T* x, const T* dy,
+                                             const T* y, const float* mean, const float* rstd, int c0, int relu) const {
+    float xv[8], gv[8];
+    ffa_load8<T>(x + off, xv);
+    ffa_load8<T>(dy + off, gv);
+    if (relu) {
+      float yv[8];
+      ffa_load8<T>(y + off, yv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gv[e] = yv[e] > 0.f ? gv[e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a[e] += gv[e];
+      b[e] += gv[e] * (xv[e] - mean[c0 + e]) * rstd[c0 + e];
+    }
+  }
+};
+
+template <typename T, typename Op>
+__global__ void __launch_bounds__(FFA_EW_THREADS)
+channel_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
+                      const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ ws,
+                      long long npix, int C, int relu) {
+  __shared__ float red[FFA_EW_THREADS][17];
+  const int CG = C / 8;
+  const int PL = FFA_EW_THREADS / CG;
+  const int t = threadIdx.x;
+  const int cg = t % CG, pl = t / CG;
+  float a[8], b[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = b[e] = 0.f;
+  if (pl < PL) {
+    Op op;
+    for (long long p = (long long)blockIdx.x * PL + pl; p < npix; p += (long long)gridDim.x * PL)
+      op(p * C + cg * 8, a, b, x, dy, y, mean, rstd, cg * 8, relu);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[t][e] = a[e];
+    red[t][8 + e] = b[e];
+  }
+  __syncthreads();
+  for (int idx = t; idx < 2 * C; idx += FFA_EW_THREADS) {
+    const int which = idx / C, c = idx % C;
+    const int g = c / 8, e = (c % 8) + which * 8;
+    float s = 0.f;
+    for (int q = 0; q < PL; ++q) s += red[q * CG + g][e];
+    ws[((long long)blockIdx.x * 2 + which) * C + c] = s;
+  }
+}
+
+static int reduce_blocks(long long npix, int C) {
+  const int PL = FFA_EW_THREADS / (C / 8);
+  long long g = (npix + (long long)PL * 8 - 1) / ((long long)PL * 8);  // >= 8 pixels per thread
+  if (g > FFA_MAX_PARTIALS) g = FFA_MAX_PARTIALS;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" long long ffa_bn_workspace_bytes(int C) { return (long long)FFA_MAX_PARTIALS * 2 * C * sizeof(float); }
+
+__global__ void bn_finalize_kernel(const float* __restrict__ ws, int nparts, double count, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                   float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int p = 0; p < nparts; ++p) {
+    s += (double)ws[((long long)p * 2 + 0) * C + c];
+    q += (double)ws[((long long)p * 2 + 1) * C + c];
+  }
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f;
+  const float bt = beta ? beta[c] : 0.f;
+  const float sc = g * rstd;
+  scale[c] = sc;
+  shift[c] = bt - (float)mean * sc;
+  mean_out[c] = (float)mean;
+  rstd_out[c] = rstd;
+  if (running_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// Training-mode statistics of x[N][C] -> scale/shift (= gamma*rstd, beta - mean*gamma*rstd), saved
+// mean/rstd for the backward pass, running-stat update (momentum convention of torch.nn.BatchNorm2d).
+extern "C" int ffa_bn_stats(int dtype, const void* x, long long npix, int C, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                            float* shift, float* mean_out, float* rstd_out, void* workspace, long long workspace_bytes,
+                            hipStream_t stream) {
+  FFA_REQUIRE(x && scale && shift && mean_out && rstd_out && workspace, "bn_stats: null pointer");
+  FFA_REQUIRE(C % 8 == 0 && C >= 8 && C <= 8 * FFA_EW_THREADS, "bn_stats: unsupported channel count %d", C);
+  FFA_REQUIRE(npix > 0, "bn_stats: empty input");
+  if (workspace_bytes < ffa_bn_workspace_bytes(C)) {
+    ffa_set_error("bn_stats: workspace too small");
+    return FFA_ERR_WORKSPACE;
+  }
+  const int nb = reduce_blocks(npix, C);
+  float* ws = static_cast<float*>(workspace);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL((channel_reduce_kernel<ffa_bf16, StatOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
+                       (const ffa_bf16*)x, (const ffa_bf16*)nullptr, (const ffa_bf16*)nullptr, nullptr, nullptr, ws,
+                       npix, C, 0);
+  else
+    hipLaunchKernelGGL((channel_reduce_kernel<float, StatOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
+                       (const float*)x, (const float*)nullptr, (const float*)nullptr, nullptr, nullptr, ws, npix, C, 0);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ffa_cdiv(C, 128)), dim3(128), 0, stream, ws, nb, (double)npix, C, gamma,
+                     beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, rstd_out);
+  return ffa_check_launch("bn_stats");
+}
+
+__global__ void bn_eval_params_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                      float eps, float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rstd = 1.f / sqrtf(running_var[c] + eps);
+  const float sc = (gamma ? gamma[c] : 1.f) * rstd;
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - running_mean[c] * sc;
+}
+
+// Eval-mode affine of a BatchNorm2d: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale.
+// The scale is folded into the packed conv weights (ffa_pack_conv_weight), the shift becomes the conv bias.
+extern "C" int ffa_bn_eval_params(int C, const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* scale, float* shift,
+                                  hipStream_t stream) {
+  FFA_REQUIRE(running_mean && running_var && scale && shift, "bn_eval_params: null pointer");
+  hipLaunchKernelGGL(bn_eval_params_kernel, dim3(ffa_cdiv(C, 128)), dim3(128), 0, stream, C, gamma, beta,
+                     running_mean, running_var, eps, scale, shift);
+  return ffa_check_launch("bn_eval_params");
+}
+
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                const float* __restrict__ scale, const float* __restrict__ shift, long long nvec, int C,
+                                int relu) {
+  const int CG = C / 8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % CG) * 8;
+    float v[8];
+    ffa_load8<T>(x + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * scale[c0 + e] + shift[c0 + e];
+    if (res) {
+      float r[8];
+      ffa_load8<T>(res + i * 8, r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    ffa_store8<T>(y + i * 8, v);
+  }
+}
+
+// y = relu?( x * scale[c] + shift[c] (+ residual) )
+extern "C" int ffa_bn_apply(int dtype, const void* x, const void* residual, void* y, const float* scale,
+                            const float* shift, long long npix, int C, int relu, hipStream_t stream) {
+  FFA_REQUIRE(x && y && scale && shift && C % 8 == 0, "bn_apply: bad arguments");
+  const long long nvec = npix * (C / 8);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(bn_apply_kernel<ffa_bf16>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const ffa_bf16*)x, (const ffa_bf16*)residual, (ffa_bf16*)y, scale, shift, nvec, C, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream, (const float*)x,
+                       (const float*)residual, (float*)y, scale, shift, nvec, C, relu);
+  return ffa_check_launch("bn_apply");
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ ws, int nparts, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int p = 0; p < nparts; ++p) {
+    s += (double)ws[((long long)p * 2 + 0) * C + c];
+    q += (double)ws[((long long)p * 2 + 1) * C + c];
+  }
+  dbeta[c] = (float)s;
+  dgamma[c] = (float)q;
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
+                                    const float* __restrict__ gamma, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ dgamma,
+                                    const float* __restrict__ dbeta, T* __restrict__ dx, T* __restrict__ dres,
+                                    long long nvec, int C, int relu, float inv_count) {
+  const int CG = C / 8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % CG) * 8;
+    float xv[8], gv[8];
+    ffa_load8<T>(x + i * 8, xv);
+    ffa_load8<T>(dy + i * 8, gv);
+    if (relu) {
+      float yv[8];
+      ffa_load8<T>(y + i * 8, yv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gv[e] = yv[e] > 0.f ? gv[e] : 0.f;
+    }
+    if (dres) ffa_store8<T>(dres + i * 8, gv);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      const float xhat = (xv[e] - mean[c]) * rstd[c];
+      const float g = gamma ? gamma[c] : 1.f;
+      o[e] = g * rstd[c] * (gv[e] - dbeta[c] * inv_count - xhat * dgamma[c] * inv_count);
+    }
+    ffa_store8<T>(dx + i * 8, o);
+  }
+}
+
+// Backward of y = relu?(bn_train(x) (+ residual)).  Inputs: x (pre-norm conv output), dy, y (only read
+// when relu), saved mean/rstd.  Outputs: dx, dgamma, dbeta and -- when dres is non-null -- the gradient
+// of the residual branch (dy masked by the ReLU).
+extern "C" int ffa_bn_bwd(int dtype, const void* x, const void* dy, const void* y, const float* gamma,
+                          const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta,
+                          long long npix, int C, int relu, void* workspace, long long workspace_bytes,
+                          hipStream_t stream) {
+  FFA_REQUIRE(x && dy && dx && mean && rstd && dgamma && dbeta && workspace, "bn_bwd: null pointer");
+  FFA_REQUIRE(!relu || y, "bn_bwd: relu needs the forward output");
+  FFA_REQUIRE(C % 8 == 0 && C >= 8 && C <= 8 * FFA_EW_THREADS, "bn_bwd: unsupported channel count %d", C);
+  if (workspace_bytes < ffa_bn_workspace_bytes(C)) {
+    ffa_set_error("bn_bwd: workspace too small");
+    return FFA_ERR_WORKSPACE;
+  }
+  const int nb = reduce_blocks(npix, C);
+  float* ws = static_cast<float*>(workspace);
+  const long long nvec = npix * (C / 8);
+  const float inv_count = (float)(1.0 / (double)npix);
+  if (dtype == FFA_BF16) {
+    hipLaunchKernelGGL((channel_reduce_kernel<ffa_bf16, BnBwdOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
+                       (const ffa_bf16*)x, (const ffa_bf16*)dy, (const ffa_bf16*)y, mean, rstd, ws, npix, C, relu);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ffa_cdiv(C, 128)), dim3(128), 0, stream, ws, nb, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<ffa_bf16>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const ffa_bf16*)x, (const ffa_bf16*)dy, (const ffa_bf16*)y, gamma, mean, rstd, dgamma, dbeta,
+                       (ffa_bf16*)dx, (ffa_bf16*)dres, nvec, C, relu, inv_count);
+  } else {
+    hipLaunchKernelGGL((channel_reduce_kernel<float, BnBwdOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
+                       (const float*)x, (const float*)dy, (const float*)y, mean, rstd, ws, npix, C, relu);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ffa_cdiv(C, 128)), dim3(128), 0, stream, ws, nb, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const float*)x, (const float*)dy, (const float*)y, gamma, mean, rstd, dgamma, dbeta,
+                       (float*)dx, (float*)dres, nvec, C, relu, inv_count);
+  }
+  return ffa_check_launch("bn_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2d(kernel 3, stride 2, padding 1), floor mode, -inf padding; ties -> first tap in row-major
+// window order (the element ATen's CPU kernel keeps: strict '>' while scanning), recorded as a
+// window-local index 0..8 so the backward pass routes gradients exactly like the reference.
+
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int B, int H,
+                                   int W, int C, int Ho, int Wo) {
+  const int CG = C / 8;
+  const long long total = (long long)B * Ho * Wo * CG;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % CG);
+    long long p = i / CG;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const long long b = p / Ho;
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      best[e] = -INFINITY;
+      bi[e] = 0;
+    }
+    bool first = true;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int iy = oy * 2 - 1 + r;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int ix = ox * 2 - 1 + s;
+        if (ix < 0 || ix >= W) continue;
+        float v[8];
+        ffa_load8<T>(x + ((b * H + iy) * W + ix) * C + g * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (first || v[e] > best[e] || v[e] != v[e]) {
+            best[e] = v[e];
+            bi[e] = r * 3 + s;
+          }
+        }
+        first = false;
+      }
+    }
+    ffa_store8<T>(y + i * 8, best);
+    uint32_t lo = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    uint32_t hi = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+    *reinterpret_cast<uint2*>(idx + i * 8) = make_uint2(lo, hi);
+  }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx, int B,
+                                   int H, int W, int C, int Ho, int Wo) {
+  // gather form: input pixel (iy, ix) is tap (r, s) of output (oy, ox) when iy = 2*oy - 1 + r
+  const int CG = C / 8;
+  const long long total = (long long)B * H * W * CG;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % CG);
+    long long p = i / CG;
+    const int ix = (int)(p % W);
+    p /= W;
+    const int iy = (int)(p % H);
+    const long long b = p / H;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int ty = iy + 1 - r;
+      if (ty < 0 || (ty & 1)) continue;
+      const int oy = ty >> 1;
+      if (oy >= Ho) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int tx = ix + 1 - s;
+        if (tx < 0 || (tx & 1)) continue;
+        const int ox = tx >> 1;
+        if (ox >= Wo) continue;
+        const long long o = (((b * Ho + oy) * Wo + ox) * CG + g) * 8;
+        const uint2 k = *reinterpret_cast<const uint2*>(idx + o);
+        float gv[8];
+        ffa_load8<T>(dy + o, gv);
+        const int tap = r * 3 + s;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t word = e < 4 ? k.x : k.y;
+          const int w = (word >> (8 * (e & 3))) & 0xff;
+          if (w == tap) acc[e] += gv[e];
+        }
+      }
+    }
+    ffa_store8<T>(dx + i * 8, acc);
+  }
+}
+
+extern "C" int ffa_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int C,
+                                    hipStream_t stream) {
+  FFA_REQUIRE(x && y && idx && C % 8 == 0, "maxpool_fwd: bad arguments");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long items = (long long)B * Ho * Wo * (C / 8);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<ffa_bf16>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const ffa_bf16*)x, (ffa_bf16*)y, idx, B, H, W, C, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const float*)x, (float*)y, idx, B, H, W, C, Ho, Wo);
+  return ffa_check_launch("maxpool_fwd");
+}
+
+extern "C" int ffa_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int B, int H, int W,
+                                    int C, hipStream_t stream) {
+  FFA_REQUIRE(dy && dx && idx && C % 8 == 0, "maxpool_bwd: bad arguments");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long items = (long long)B * H * W * (C / 8);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<ffa_bf16>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const ffa_bf16*)dy, idx, (ffa_bf16*)dx, B, H, W, C, Ho, Wo);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const float*)dy, idx, (float*)dx, B, H, W, C, Ho, Wo);
+  return ffa_check_launch("maxpool_bwd");
+}

@@ -1,0 +1,545 @@
+// Decoder resampling and the per-pixel loss / prediction kernels (all HBM-bound, NHWC).
+//
+//   * nearest x2 upsample + channel concat (smp UnetDecoder's DecoderBlock: F.interpolate(scale 2,
+//     'nearest') then torch.cat([x, skip], 1)) forward and backward
+//   * bilinear resize, align_corners=False (flair_hub/models/flair_model.py:318-327 interpolate_map)
+//     forward and backward
+//   * weighted softmax cross-entropy forward + dlogits + argmax in ONE pass over the logits
+//     (flair_hub/tasks/module_setup.py:150-161 nn.CrossEntropyLoss(weight=w);
+//      flair_hub/tasks/tasks_module.py:155,158 loss + argmax(softmax(logits)))
+//   * margin crop + argmax -> uint8 (flair_zonal_detection/inference.py:300 +
+//     flair_zonal_detection/postprocess.py:25-27) and class_prob -> round(softmax*255) (:19-23)
+//   * one-hot -> index (tasks_module.py:153)
+#include "ffa_common.h"
+
+#define FFA_EW_THREADS 256
+
+static inline int ew_grid(long long items) {
+  long long g = (items + FFA_EW_THREADS - 1) / FFA_EW_THREADS;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// nearest x2 + concat
+
+template <typename T>
+__global__ void up2_concat_fwd_kernel(const T* __restrict__ lo, const T* __restrict__ skip, T* __restrict__ out, int B,
+                                      int Hl, int Wl, int C1, int C2) {
+  const int H = Hl * 2, W = Wl * 2, C = C1 + C2;
+  const int CG = C / 8, CG1 = C1 / 8;
+  const long long total = (long long)B * H * W * CG;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % CG);
+    long long p = i / CG;
+    const int x = (int)(p % W);
+    p /= W;
+    const int y = (int)(p % H);
+    const long long b = p / H;
+    ffa_u32x4 v0, v1;
+    const T* src;
+    if (g < CG1)
+      src = lo + ((b * Hl + (y >> 1)) * Wl + (x >> 1)) * C1 + g * 8;
+    else
+      src = skip + ((b * H + y) * W + x) * C2 + (g - CG1) * 8;
+    v0 = reinterpret_cast<const ffa_u32x4*>(src)[0];
+    if (sizeof(T) == 4) v1 = reinterpret_cast<const ffa_u32x4*>(src)[1];
+    ffa_u32x4* dst = reinterpret_cast<ffa_u32x4*>(out + i * 8);
+    dst[0] = v0;
+    if (sizeof(T) == 4) dst[1] = v1;
+  }
+}
+
+template <typename T>
+__global__ void up2_concat_bwd_kernel(const T* __restrict__ dcat, T* __restrict__ dlo, T* __restrict__ dskip, int B,
+                                      int Hl, int Wl, int C1, int C2) {
+  // item space: first the low-res pixels x C1 groups (sum of the 4 children), then the skip copy
+  const int H = Hl * 2, W = Wl * 2, C = C1 + C2;
+  const int CG1 = C1 / 8, CG2 = C2 / 8;
+  const long long n_lo = (long long)B * Hl * Wl * CG1;
+  const long long n_sk = dskip ? (long long)B * H * W * CG2 : 0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n_lo + n_sk;
+       i += (long long)gridDim.x * blockDim.x) {
+    if (i < n_lo) {
+      const int g = (int)(i % CG1);
+      long long p = i / CG1;
+      const int x = (int)(p % Wl);
+      p /= Wl;
+      const int y = (int)(p % Hl);
+      const long long b = p / Hl;
+      float acc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+        for (int dxx = 0; dxx < 2; ++dxx) {
+          float v[8];
+          ffa_load8<T>(dcat + ((b * H + 2 * y + dyy) * W + 2 * x + dxx) * C + g * 8, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+      ffa_store8<T>(dlo + i * 8, acc);
+    } else {
+      const long long k = i - n_lo;
+      const int g = (int)(k % CG2);
+      const long long p = k / CG2;
+      float v[8];
+      ffa_load8<T>(dcat + p * C + C1 + g * 8, v);
+      ffa_store8<T>(dskip + k * 8, v);
+    }
+  }
+}
+
+extern "C" int ffa_upsample_nearest2x_concat_fwd(int dtype, const void* lo, const void* skip, void* out, int B, int Hl,
+                                                 int Wl, int C1, int C2, hipStream_t stream) {
+  FFA_REQUIRE(lo && out && C1 % 8 == 0 && C2 % 8 == 0 && (C2 == 0 || skip), "up2_concat_fwd: bad arguments");
+  const long long items = (long long)B * Hl * 2 * Wl * 2 * ((C1 + C2) / 8);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(up2_concat_fwd_kernel<ffa_bf16>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const ffa_bf16*)lo, (const ffa_bf16*)skip, (ffa_bf16*)out, B, Hl, Wl, C1, C2);
+  else
+    hipLaunchKernelGGL(up2_concat_fwd_kernel<float>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const float*)lo, (const float*)skip, (float*)out, B, Hl, Wl, C1, C2);
+  return ffa_check_launch("up2_concat_fwd");
+}
+
+extern "C" int ffa_upsample_nearest2x_concat_bwd(int dtype, const void* dcat, void* dlo, void* dskip, int B, int Hl,
+                                                 int Wl, int C1, int C2, hipStream_t stream) {
+  FFA_REQUIRE(dcat && dlo && C1 % 8 == 0 && C2 % 8 == 0 && (C2 == 0 || dskip), "up2_concat_bwd: bad arguments");
+  const long long items = (long long)B * Hl * Wl * (C1 / 8) + (long long)B * Hl * 2 * Wl * 2 * (C2 / 8);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(up2_concat_bwd_kernel<ffa_bf16>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const ffa_bf16*)dcat, (ffa_bf16*)dlo, (ffa_bf16*)(C2 ? dskip : nullptr), B, Hl, Wl, C1, C2);
+  else
+    hipLaunchKernelGGL(up2_concat_bwd_kernel<float>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const float*)dcat, (float*)dlo, (float*)(C2 ? dskip : nullptr), B, Hl, Wl, C1, C2);
+  return ffa_check_launch("up2_concat_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilinear, align_corners=False.  Source index as ATen computes it (area_pixel_compute_source_index):
+//   src = max(0, scale * (dst + 0.5) - 0.5), scale = in / out in f32, i0 = (int)src,
+//   i1 = i0 + (i0 < in - 1), lambda1 = src - i0, lambda0 = 1 - lambda1
+
+__device__ __forceinline__ void bilinear_src(int dst, float scale, int in_size, int& i0, int& i1, float& l0,
+                                             float& l1) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
+template <typename T>
+__global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Hi, int Wi, int Ho, int Wo,
+                                    int C, float sy, float sx) {
+  const int CG = C / 8;
+  const long long total = (long long)B * Ho * Wo * CG;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % CG);
+    long long p = i / CG;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const long long b = p / Ho;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    bilinear_src(oy, sy, Hi, y0, y1, ly0, ly1);
+    bilinear_src(ox, sx, Wi, x0, x1, lx0, lx1);
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    ffa_load8<T>(x + ((b * Hi + y0) * Wi + x0) * C + g * 8, v00);
+    ffa_load8<T>(x + ((b * Hi + y0) * Wi + x1) * C + g * 8, v01);
+    ffa_load8<T>(x + ((b * Hi + y1) * Wi + x0) * C + g * 8, v10);
+    ffa_load8<T>(x + ((b * Hi + y1) * Wi + x1) * C + g * 8, v11);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      o[e] = ly0 * (lx0 * v00[e] + lx1 * v01[e]) + ly1 * (lx0 * v10[e] + lx1 * v11[e]);
+    ffa_store8<T>(y + i * 8, o);
+  }
+}
+
+template <typename T>
+__global__ void bilinear_bwd_kernel(const T* __restrict__ dy, float* __restrict__ dx32, int B, int Hi, int Wi, int Ho,
+                                    int Wo, int C, float sy, float sx) {
+  // scatter with f32 atomics into a zeroed f32 image (not on the U-Net@512 path, where the resize is
+  // the identity and is elided); converted to the storage dtype by bilinear_bwd_cast_kernel
+  const int CG = C / 8;
+  const long long total = (long long)B * Ho * Wo * CG;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % CG);
+    long long p = i / CG;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const long long b = p / Ho;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    bilinear_src(oy, sy, Hi, y0, y1, ly0, ly1);
+    bilinear_src(ox, sx, Wi, x0, x1, lx0, lx1);
+    float gv[8];
+    ffa_load8<T>(dy + i * 8, gv);
+    float* d00 = dx32 + ((b * Hi + y0) * Wi + x0) * C + g * 8;
+    float* d01 = dx32 + ((b * Hi + y0) * Wi + x1) * C + g * 8;
+    float* d10 = dx32 + ((b * Hi + y1) * Wi + x0) * C + g * 8;
+    float* d11 = dx32 + ((b * Hi + y1) * Wi + x1) * C + g * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      atomicAdd(d00 + e, ly0 * lx0 * gv[e]);
+      atomicAdd(d01 + e, ly0 * lx1 * gv[e]);
+      atomicAdd(d10 + e, ly1 * lx0 * gv[e]);
+      atomicAdd(d11 + e, ly1 * lx1 * gv[e]);
+    }
+  }
+}
+
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, long long nvec) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * blockDim.x) {
+    float v[8];
+    ffa_load8<float>(src + i * 8, v);
+    ffa_store8<T>(dst + i * 8, v);
+  }
+}
+
+extern "C" int ffa_bilinear_fwd(int dtype, const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                hipStream_t stream) {
+  FFA_REQUIRE(x && y && C % 8 == 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "bilinear_fwd: bad arguments");
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  const long long items = (long long)B * Ho * Wo * (C / 8);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(bilinear_fwd_kernel<ffa_bf16>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const ffa_bf16*)x, (ffa_bf16*)y, B, Hi, Wi, Ho, Wo, C, sy, sx);
+  else
+    hipLaunchKernelGGL(bilinear_fwd_kernel<float>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const float*)x, (float*)y, B, Hi, Wi, Ho, Wo, C, sy, sx);
+  return ffa_check_launch("bilinear_fwd");
+}
+
+extern "C" long long ffa_bilinear_bwd_workspace_bytes(int B, int Hi, int Wi, int C) {
+  return (long long)B * Hi * Wi * C * sizeof(float);
+}
+
+extern "C" int ffa_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                void* workspace, long long workspace_bytes, hipStream_t stream) {
+  FFA_REQUIRE(dy && dx && workspace && C % 8 == 0, "bilinear_bwd: bad arguments");
+  const long long need = ffa_bilinear_bwd_workspace_bytes(B, Hi, Wi, C);
+  if (workspace_bytes < need) {
+    ffa_set_error("bilinear_bwd: workspace too small");
+    return FFA_ERR_WORKSPACE;
+  }
+  hipError_t e = hipMemsetAsync(workspace, 0, need, stream);
+  if (e != hipSuccess) {
+    ffa_set_error("bilinear_bwd: memset failed: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  const long long items = (long long)B * Ho * Wo * (C / 8);
+  const long long nvec = (long long)B * Hi * Wi * (C / 8);
+  if (dtype == FFA_BF16) {
+    hipLaunchKernelGGL(bilinear_bwd_kernel<ffa_bf16>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const ffa_bf16*)dy, (float*)workspace, B, Hi, Wi, Ho, Wo, C, sy, sx);
+    hipLaunchKernelGGL(cast_from_f32_kernel<ffa_bf16>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const float*)workspace, (ffa_bf16*)dx, nvec);
+  } else {
+    hipLaunchKernelGGL(bilinear_bwd_kernel<float>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const float*)dy, (float*)workspace, B, Hi, Wi, Ho, Wo, C, sy, sx);
+    hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const float*)workspace, (float*)dx, nvec);
+  }
+  return ffa_check_launch("bilinear_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// weighted softmax cross-entropy.  One thread per pixel; logits [npix][Cp] (K real classes, the
+// Cp - K pad channels are ignored on read and written as zeros in dlogits so the head dgrad never
+// sees garbage).  Reduction: loss = sum_p w[t_p] * (lse_p - z_p[t_p]) / sum_p w[t_p]
+// (torch.nn.CrossEntropyLoss(weight=w, reduction='mean')).  Targets are uint8 class indices;
+// targets >= K contribute nothing (weight 0), matching ignore semantics for padded tiles.
+//
+// Pass A (ce_weight_sum_kernel) reduces sum_p w[t_p] from the targets alone (1 B/pixel);
+// pass B reads the logits once and writes per-block loss partials, dlogits (already divided by the
+// weight sum and multiplied by *grad_scale) and the per-pixel argmax.
+
+#define FFA_CE_MAXK 32
+#define FFA_CE_BLOCKS 1024
+
+__global__ void ce_weight_sum_kernel(const uint8_t* __restrict__ tgt, const float* __restrict__ w, int K,
+                                     long long npix, float* __restrict__ parts) {
+  __shared__ float red[FFA_EW_THREADS / 64];
+  float s = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npix;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int t = tgt[i];
+    s += (t < K) ? w[t] : 0.f;
+  }
+  s = ffa_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int k = 0; k < FFA_EW_THREADS / 64; ++k) tot += red[k];
+    parts[blockIdx.x] = tot;
+  }
+}
+
+__global__ void ce_finalize_sum_kernel(const float* __restrict__ parts, int n, float* __restrict__ out) {
+  // single thread, fixed order -> bitwise reproducible
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += (double)parts[i];
+    out[0] = (float)s;
+  }
+}
+
+__global__ void ce_finalize_loss_kernel(const float* __restrict__ parts, int n, const float* __restrict__ wsum,
+                                        float* __restrict__ loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += (double)parts[i];
+    loss[0] = (float)(s / (double)wsum[0]);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(FFA_EW_THREADS)
+softmax_ce_kernel(const T* __restrict__ logits, const uint8_t* __restrict__ tgt, const float* __restrict__ w,
+                  const float* __restrict__ wsum, const float* __restrict__ grad_scale, T* __restrict__ dlogits,
+                  uint8_t* __restrict__ pred, float* __restrict__ parts, long long npix, int K, int Cp) {
+  __shared__ float red[FFA_EW_THREADS / 64];
+  float lsum = 0.f;
+  float gs = 0.f;
+  if (dlogits) gs = grad_scale[0] / wsum[0];
+  const int nv = Cp / 8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npix;
+       i += (long long)gridDim.x * blockDim.x) {
+    float z[FFA_CE_MAXK];
+#pragma unroll
+    for (int v = 0; v < FFA_CE_MAXK / 8; ++v) {
+      if (v < nv) {
+        float tmp[8];
+        ffa_load8<T>(logits + i * Cp + v * 8, tmp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[v * 8 + e] = tmp[e];
+      }
+    }
+    float m = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int k = 0; k < FFA_CE_MAXK; ++k) {
+      if (k < K && z[k] > m) {  // strict '>' keeps the lowest index on ties (torch.argmax)
+        m = z[k];
+        am = k;
+      }
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < FFA_CE_MAXK; ++k) {
+      if (k < K) {
+        z[k] = __expf(z[k] - m);
+        se += z[k];
+      }
+    }
+    const int t = tgt[i];
+    const float wt = (t < K) ? w[t] : 0.f;
+    const float inv = 1.f / se;
+    // -log softmax[t] = log(se) - (z_t - m); z[k] now holds exp(z_k - m)
+    float zt = 1.f;
+#pragma unroll
+    for (int k = 0; k < FFA_CE_MAXK; ++k)
+      if (k == t) zt = z[k];
+    if (wt != 0.f) lsum += wt * (__logf(se) - __logf(zt));
+    if (pred) pred[i] = (uint8_t)am;
+    if (dlogits) {
+      const float c = wt * gs;
+#pragma unroll
+      for (int v = 0; v < FFA_CE_MAXK / 8; ++v) {
+        if (v < nv) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int k = v * 8 + e;
+            o[e] = (k < K) ? c * (z[k] * inv - (k == t ? 1.f : 0.f)) : 0.f;
+          }
+          ffa_store8<T>(dlogits + i * Cp + v * 8, o);
+        }
+      }
+    }
+  }
+  lsum = ffa_wave_sum(lsum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int k = 0; k < FFA_EW_THREADS / 64; ++k) tot += red[k];
+    parts[blockIdx.x] = tot;
+  }
+}
+
+extern "C" long long ffa_softmax_ce_workspace_bytes(void) { return (long long)(2 * FFA_CE_BLOCKS + 4) * sizeof(float); }
+
+// loss[0] = weighted-mean CE; wsum_out[0] = sum of target weights; optional dlogits (scaled by
+// grad_scale[0], a device scalar, default 1 when null is not allowed -> pass a device 1.0f) and pred.
+extern "C" int ffa_softmax_ce(int dtype, const void* logits, const uint8_t* targets, const float* class_weights,
+                              const float* grad_scale, float* loss, float* wsum_out, void* dlogits, uint8_t* pred,
+                              long long npix, int K, int Cp, void* workspace, long long workspace_bytes,
+                              hipStream_t stream) {
+  FFA_REQUIRE(logits && targets && class_weights && loss && wsum_out && workspace, "softmax_ce: null pointer");
+  FFA_REQUIRE(K >= 1 && K <= FFA_CE_MAXK && Cp % 8 == 0 && Cp >= K && Cp <= FFA_CE_MAXK,
+              "softmax_ce: unsupported class count %d (pitch %d)", K, Cp);
+  FFA_REQUIRE(!dlogits || grad_scale, "softmax_ce: dlogits needs grad_scale");
+  if (workspace_bytes < ffa_softmax_ce_workspace_bytes()) {
+    ffa_set_error("softmax_ce: workspace too small");
+    return FFA_ERR_WORKSPACE;
+  }
+  float* parts_w = static_cast<float*>(workspace);
+  float* parts_l = parts_w + FFA_CE_BLOCKS;
+  long long nb = (npix + FFA_EW_THREADS - 1) / FFA_EW_THREADS;
+  if (nb > FFA_CE_BLOCKS) nb = FFA_CE_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(ce_weight_sum_kernel, dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream, targets, class_weights, K,
+                     npix, parts_w);
+  hipLaunchKernelGGL(ce_finalize_sum_kernel, dim3(1), dim3(64), 0, stream, parts_w, (int)nb, wsum_out);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(softmax_ce_kernel<ffa_bf16>, dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream,
+                       (const ffa_bf16*)logits, targets, class_weights, wsum_out, grad_scale, (ffa_bf16*)dlogits, pred,
+                       parts_l, npix, K, Cp);
+  else
+    hipLaunchKernelGGL(softmax_ce_kernel<float>, dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream,
+                       (const float*)logits, targets, class_weights, wsum_out, grad_scale, (float*)dlogits, pred,
+                       parts_l, npix, K, Cp);
+  hipLaunchKernelGGL(ce_finalize_loss_kernel, dim3(1), dim3(64), 0, stream, parts_l, (int)nb, wsum_out, loss);
+  return ffa_check_launch("softmax_ce");
+}
+
+// ------------------------------------------------------------------------------------------------
+// prediction conversion for the zonal tile loop
+
+template <typename T>
+__global__ void argmax_crop_kernel(const T* __restrict__ logits, uint8_t* __restrict__ out, int B, int H, int W, int K,
+                                   int Cp, int y0, int x0, int h, int w) {
+  const long long total = (long long)B * h * w;
+  const int nv = Cp / 8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w);
+    long long p = i / w;
+    const int y = (int)(p % h);
+    const long long b = p / h;
+    const T* src = logits + ((b * H + y0 + y) * W + x0 + x) * Cp;
+    float m = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int v = 0; v < FFA_CE_MAXK / 8; ++v) {
+      if (v < nv) {
+        float tmp[8];
+        ffa_load8<T>(src + v * 8, tmp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = v * 8 + e;
+          if (k < K && tmp[e] > m) {
+            m = tmp[e];
+            am = k;
+          }
+        }
+      }
+    }
+    out[i] = (uint8_t)am;
+  }
+}
+
+template <typename T>
+__global__ void class_prob_crop_kernel(const T* __restrict__ logits, uint8_t* __restrict__ out, int B, int H, int W,
+                                       int K, int Cp, int y0, int x0, int h, int w) {
+  // out is [B][K][h][w] uint8 = rint(softmax * 255), rint = round-half-even like numpy.round
+  const long long total = (long long)B * h * w;
+  const int nv = Cp / 8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w);
+    long long p = i / w;
+    const int y = (int)(p % h);
+    const long long b = p / h;
+    const T* src = logits + ((b * H + y0 + y) * W + x0 + x) * Cp;
+    float z[FFA_CE_MAXK];
+#pragma unroll
+    for (int v = 0; v < FFA_CE_MAXK / 8; ++v) {
+      if (v < nv) {
+        float tmp[8];
+        ffa_load8<T>(src + v * 8, tmp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[v * 8 + e] = tmp[e];
+      }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < FFA_CE_MAXK; ++k)
+      if (k < K) m = fmaxf(m, z[k]);
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < FFA_CE_MAXK; ++k)
+      if (k < K) {
+        z[k] = expf(z[k] - m);
+        se += z[k];
+      }
+#pragma unroll
+    for (int k = 0; k < FFA_CE_MAXK; ++k)
+      if (k < K) out[((b * K + k) * h + y) * (long long)w + x] = (uint8_t)rintf(z[k] / se * 255.f);
+  }
+}
+
+// mode 0: argmax -> out [B][h][w]; mode 1: class_prob -> out [B][K][h][w]
+extern "C" int ffa_predict_u8(int dtype, int mode, const void* logits, uint8_t* out, int B, int H, int W, int K,
+                              int Cp, int y0, int x0, int h, int w, hipStream_t stream) {
+  FFA_REQUIRE(logits && out, "predict_u8: null pointer");
+  FFA_REQUIRE(K >= 1 && K <= FFA_CE_MAXK && Cp % 8 == 0 && Cp >= K && Cp <= FFA_CE_MAXK,
+              "predict_u8: unsupported class count %d (pitch %d)", K, Cp);
+  FFA_REQUIRE(y0 >= 0 && x0 >= 0 && h > 0 && w > 0 && y0 + h <= H && x0 + w <= W, "predict_u8: crop outside the tile");
+  FFA_REQUIRE(mode == 0 || mode == 1, "predict_u8: unknown mode %d", mode);
+  const long long items = (long long)B * h * w;
+#define FFA_PRED(KER, TT) \
+  hipLaunchKernelGGL(KER<TT>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream, (const TT*)logits, out, B, H, W, K, Cp, y0, x0, h, w)
+  if (mode == 0) {
+    if (dtype == FFA_BF16) FFA_PRED(argmax_crop_kernel, ffa_bf16); else FFA_PRED(argmax_crop_kernel, float);
+  } else {
+    if (dtype == FFA_BF16) FFA_PRED(class_prob_crop_kernel, ffa_bf16); else FFA_PRED(class_prob_crop_kernel, float);
+  }
+#undef FFA_PRED
+  return ffa_check_launch("predict_u8");
+}
+
+__global__ void onehot_to_index_kernel(const float* __restrict__ onehot, uint8_t* __restrict__ idx, int B, int K,
+                                       long long hw) {
+  // NCHW one-hot (the reference's label format, flair_hub/data/utils_data/label.py:3-14) -> class index,
+  // first maximum wins like torch.argmax
+  const long long total = (long long)B * hw;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / hw, p = i % hw;
+    float m = -INFINITY;
+    int am = 0;
+    for (int k = 0; k < K; ++k) {
+      const float v = onehot[(b * K + k) * hw + p];
+      if (v > m) {
+        m = v;
+        am = k;
+      }
+    }
+    idx[i] = (uint8_t)am;
+  }
+}
+
+extern "C" int ffa_onehot_to_index(const float* onehot, uint8_t* idx, int B, int K, int H, int W, hipStream_t stream) {
+  FFA_REQUIRE(onehot && idx && K >= 1 && K <= 255, "onehot_to_index: bad arguments");
+  const long long items = (long long)B * H * W;
+  hipLaunchKernelGGL(onehot_to_index_kernel, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream, onehot, idx, B, K,
+                     (long long)H * W);
+  return ffa_check_launch("onehot_to_index");
+}

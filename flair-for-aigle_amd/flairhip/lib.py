@@ -1,0 +1,98 @@
+"""ctypes binding of libflairhip.so (the C ABI declared in include/flairhip.h).
+
+Only plain pointers and integers cross this boundary; torch tensors are reduced to
+``data_ptr()`` by ``flairhip.ops``.  There is no CPU fallback: if the shared library is missing
+the import of the product path fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflairhip.so")
+
+BF16 = 0
+F32 = 1
+
+
+class FlairHipError(RuntimeError):
+    pass
+
+
+class Tile(C.Structure):
+    _fields_ = [
+        ("left", C.c_double), ("bottom", C.c_double), ("right", C.c_double), ("top", C.c_double),
+        ("x0", C.c_double), ("y0", C.c_double), ("x1", C.c_double), ("y1", C.c_double),
+        ("row", C.c_longlong), ("col", C.c_longlong),
+    ]
+
+
+class Window(C.Structure):
+    _fields_ = [("col_off", C.c_int), ("row_off", C.c_int), ("width", C.c_int), ("height", C.c_int),
+                ("skip", C.c_int)]
+
+
+_i, _ll, _p, _f, _d = C.c_int, C.c_longlong, C.c_void_p, C.c_float, C.c_double
+
+# name -> (restype, argtypes); mirrors include/flairhip.h one to one
+SIGNATURES = {
+    "ffa_last_error": (C.c_char_p, []),
+    "ffa_version": (_i, []),
+    "ffa_target_arch": (C.c_char_p, []),
+    "ffa_conv_block_co": (_i, [_i, _i, _i, _i]),
+    "ffa_conv_row_group": (_i, [_i]),
+    "ffa_pack_conv_weight_bytes": (_ll, [_i, _i, _i, _i, _i]),
+    "ffa_pack_conv_weight": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "ffa_conv2d": (_i, [_i, _p, _p, _p, _p, _p] + [_i] * 15 + [_p]),
+    "ffa_conv_wgrad_workspace_bytes": (_ll, [_i] * 9),
+    "ffa_conv_wgrad": (_i, [_i, _p, _p, _p] + [_i] * 14 + [_p, _ll, _p]),
+    "ffa_bn_workspace_bytes": (_ll, [_i]),
+    "ffa_bn_stats": (_i, [_i, _p, _ll, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _ll, _p]),
+    "ffa_bn_eval_params": (_i, [_i, _p, _p, _p, _p, _f, _p, _p, _p]),
+    "ffa_bn_apply": (_i, [_i, _p, _p, _p, _p, _p, _ll, _i, _i, _p]),
+    "ffa_bn_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p, _ll, _p]),
+    "ffa_maxpool3x3s2_fwd": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "ffa_maxpool3x3s2_bwd": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "ffa_nchw_to_nhwc": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "ffa_nhwc_to_nchw": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "ffa_upsample_nearest2x_concat_fwd": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "ffa_upsample_nearest2x_concat_bwd": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "ffa_bilinear_fwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "ffa_bilinear_bwd_workspace_bytes": (_ll, [_i, _i, _i, _i]),
+    "ffa_bilinear_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
+    "ffa_softmax_ce_workspace_bytes": (_ll, []),
+    "ffa_softmax_ce": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p, _ll, _p]),
+    "ffa_predict_u8": (_i, [_i, _i, _p, _p] + [_i] * 9 + [_p]),
+    "ffa_onehot_to_index": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "ffa_slice_grid": (_ll, [_d, _d, _d, _d, _d, _d, _i, _i, _d, C.POINTER(Tile), _ll]),
+    "ffa_write_window": (_i, [_d, _d, _d, _d, _d, _d, _d, _i, _i, C.POINTER(Window)]),
+    "ffa_probe_tr16": (_i, [_p, _p, _p]),
+    "ffa_probe_mfma": (_i, [_p, _p, _p, _i, _p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libflairhip.so once; raise FlairHipError (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FlairHipError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950); "
+            "there is no CPU fallback for the HIP hot path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library out of sync
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().ffa_last_error().decode("utf-8", "replace")
+        raise FlairHipError(f"{what or 'libflairhip'} failed (code {rc}): {msg}")

@@ -1,0 +1,383 @@
+"""Functional layer over the C ABI: torch tensors in, torch tensors out, no autograd.
+
+PyTorch is used here for device memory and the current HIP stream only.  Activations are
+contiguous NHWC tensors ``[B, H, W, C]`` (bf16 or f32) whose channel count is a multiple of 16;
+every function launches on ``torch.cuda.current_stream()`` and returns immediately.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import lib as _l
+
+CH_ALIGN = 16
+
+
+def pad_channels(c: int, align: int = CH_ALIGN) -> int:
+    return (c + align - 1) // align * align
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return _l.BF16
+    if t.dtype == torch.float32:
+        return _l.F32
+    raise TypeError(f"flairhip: unsupported dtype {t.dtype}")
+
+
+def _dtype_id(dtype: torch.dtype) -> int:
+    return _l.BF16 if dtype == torch.bfloat16 else _l.F32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk_nhwc(t: torch.Tensor, name: str) -> None:
+    if not (t.is_cuda and t.dim() == 4 and t.is_contiguous()):
+        raise ValueError(f"flairhip: {name} must be a contiguous CUDA NHWC tensor, got {tuple(t.shape)} "
+                         f"strides {t.stride()} on {t.device}")
+
+
+_workspaces = {}
+
+
+def workspace(nbytes: int, device: torch.device, slot: str = "default") -> torch.Tensor:
+    """Grow-only scratch buffer per (device, slot); the library itself never allocates."""
+    key = (device.index, slot)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+# --------------------------------------------------------------------------------------------------
+# convolution
+
+@dataclass
+class PackedWeight:
+    data: torch.Tensor  # packed operand (opaque bytes viewed as the compute dtype)
+    rows: int           # padded row count (output channels of the GEMM)
+    rows_real: int
+    ci_pitch: int       # channel pitch of the activation it multiplies
+    bco: int
+    kh: int
+    kw: int
+    stride: int         # stride of the conv the operand is used for (1 for every dgrad operand)
+
+
+def pack_conv_weight(w_oihw: torch.Tensor, dtype: torch.dtype, stride: int, ci_pitch: int,
+                     transpose: bool = False, scale: Optional[torch.Tensor] = None) -> PackedWeight:
+    """OIHW f32 master weight -> MFMA operand for ffa_conv2d (forward, or dgrad when transpose=True)."""
+    lib = _l.load()
+    if w_oihw.dtype != torch.float32 or not w_oihw.is_contiguous():
+        raise ValueError("pack_conv_weight: master weight must be contiguous f32 OIHW")
+    O, I, kh, kw = w_oihw.shape
+    rows_real = I if transpose else O
+    use_stride = 1 if transpose else stride
+    bco = lib.ffa_conv_block_co(kh, kw, use_stride, rows_real)
+    if bco <= 0:
+        raise _l.FlairHipError(f"no conv kernel for {kh}x{kw} stride {use_stride}")
+    rows = (rows_real + bco - 1) // bco * bco
+    rg = lib.ffa_conv_row_group(kh)
+    did = _dtype_id(dtype)
+    nbytes = lib.ffa_pack_conv_weight_bytes(did, rows, ci_pitch, kh, kw)
+    dst = torch.empty(nbytes // (2 if dtype == torch.bfloat16 else 4), dtype=dtype, device=w_oihw.device)
+    _l.check(lib.ffa_pack_conv_weight(did, w_oihw.data_ptr(), _ptr(scale), dst.data_ptr(), O, I, kh, kw,
+                                      1 if transpose else 0, rows, ci_pitch, bco, rg, _stream()), "pack_conv_weight")
+    return PackedWeight(dst, rows, rows_real, ci_pitch, bco, kh, kw, use_stride)
+
+
+def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:
+    return (h + 2 * pad - k) // stride + 1
+
+
+def conv2d(x: torch.Tensor, w: PackedWeight, pad: int, out_channels: int, bias: Optional[torch.Tensor] = None,
+           residual: Optional[torch.Tensor] = None, relu: bool = False, dil: int = 1,
+           out_hw: Optional[Tuple[int, int]] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[B,Ho,Wo,out_channels] = relu?(conv(x, w) + bias + residual).  out_channels is the stored pitch."""
+    lib = _l.load()
+    _chk_nhwc(x, "conv input")
+    B, Hi, Wi, Ci = x.shape
+    if Ci != w.ci_pitch:
+        raise ValueError(f"conv2d: input pitch {Ci} != packed pitch {w.ci_pitch}")
+    if out_hw is None:
+        hv, wv = (Hi * 2, Wi * 2) if dil == 2 else (Hi, Wi)
+        out_hw = (conv_out_size(hv, w.kh, w.stride, pad), conv_out_size(wv, w.kw, w.stride, pad))
+    Ho, Wo = out_hw
+    if out is None:
+        out = torch.empty((B, Ho, Wo, out_channels), dtype=x.dtype, device=x.device)
+    if residual is not None and residual.shape != out.shape:
+        raise ValueError("conv2d: residual shape mismatch")
+    if bias is not None and bias.numel() < out_channels:
+        raise ValueError("conv2d: bias shorter than the output pitch")
+    _l.check(lib.ffa_conv2d(_dt(x), x.data_ptr(), w.data.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
+                            B, Hi, Wi, Ci, Ho, Wo, out_channels, w.rows, w.bco, w.kh, w.kw, w.stride, pad, dil,
+                            1 if relu else 0, _stream()), "conv2d")
+    return out
+
+
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, co_real: int, ci_real: int, kh: int, kw: int, stride: int,
+               pad: int, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """dW (OIHW f32, [co_real, ci_real, kh, kw]) from the conv input x and the output gradient dy."""
+    lib = _l.load()
+    _chk_nhwc(x, "wgrad input")
+    _chk_nhwc(dy, "wgrad dy")
+    B, Hi, Wi, Ci = x.shape
+    _, Ho, Wo, Co = dy.shape
+    did = _dt(x)
+    need = lib.ffa_conv_wgrad_workspace_bytes(did, kh, kw, stride, Co, Ci, B, Ho, Wo)
+    if need < 0:
+        raise _l.FlairHipError(f"no wgrad kernel for {kh}x{kw} stride {stride}")
+    ws = workspace(need, x.device, "wgrad")
+    if out is None:
+        out = torch.empty((co_real, ci_real, kh, kw), dtype=torch.float32, device=x.device)
+    _l.check(lib.ffa_conv_wgrad(did, x.data_ptr(), dy.data_ptr(), out.data_ptr(), B, Hi, Wi, Ci, Ho, Wo, Co, co_real,
+                                ci_real, kh, kw, stride, pad, 1 if accumulate else 0, ws.data_ptr(), ws.numel(),
+                                _stream()), "conv_wgrad")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# normalisation / pooling
+
+def bn_stats(x: torch.Tensor, gamma, beta, running_mean, running_var, momentum: float, eps: float):
+    """Batch statistics of x (NHWC) -> (scale, shift, mean, rstd); updates the running buffers in place."""
+    lib = _l.load()
+    _chk_nhwc(x, "bn input")
+    C_ = x.shape[-1]
+    npix = x.numel() // C_
+    dev = x.device
+    out = torch.empty((4, C_), dtype=torch.float32, device=dev)
+    ws = workspace(lib.ffa_bn_workspace_bytes(C_), dev, "bn")
+    _l.check(lib.ffa_bn_stats(_dt(x), x.data_ptr(), npix, C_, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                              _ptr(running_var), momentum, eps, out[0].data_ptr(), out[1].data_ptr(),
+                              out[2].data_ptr(), out[3].data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "bn_stats")
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_eval_params(gamma, beta, running_mean, running_var, eps: float):
+    lib = _l.load()
+    C_ = running_mean.numel()
+    out = torch.empty((2, C_), dtype=torch.float32, device=running_mean.device)
+    _l.check(lib.ffa_bn_eval_params(C_, _ptr(gamma), _ptr(beta), running_mean.data_ptr(), running_var.data_ptr(), eps,
+                                    out[0].data_ptr(), out[1].data_ptr(), _stream()), "bn_eval_params")
+    return out[0], out[1]
+
+
+def bn_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, residual: Optional[torch.Tensor] = None,
+             relu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _l.load()
+    _chk_nhwc(x, "bn_apply input")
+    C_ = x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    _l.check(lib.ffa_bn_apply(_dt(x), x.data_ptr(), _ptr(residual), out.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                              x.numel() // C_, C_, 1 if relu else 0, _stream()), "bn_apply")
+    return out
+
+
+def bn_bwd(x: torch.Tensor, dy: torch.Tensor, y: Optional[torch.Tensor], gamma, mean, rstd, relu: bool,
+           want_dres: bool):
+    """-> (dx, dres or None, dgamma, dbeta)."""
+    lib = _l.load()
+    C_ = x.shape[-1]
+    dev = x.device
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    dgb = torch.empty((2, C_), dtype=torch.float32, device=dev)
+    ws = workspace(lib.ffa_bn_workspace_bytes(C_), dev, "bn")
+    _l.check(lib.ffa_bn_bwd(_dt(x), x.data_ptr(), dy.data_ptr(), _ptr(y), _ptr(gamma), mean.data_ptr(),
+                            rstd.data_ptr(), dx.data_ptr(), _ptr(dres), dgb[0].data_ptr(), dgb[1].data_ptr(),
+                            x.numel() // C_, C_, 1 if relu else 0, ws.data_ptr(), ws.numel(), _stream()), "bn_bwd")
+    return dx, dres, dgb[0], dgb[1]
+
+
+def maxpool3x3s2_fwd(x: torch.Tensor):
+    lib = _l.load()
+    _chk_nhwc(x, "maxpool input")
+    B, H, W, C_ = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((B, Ho, Wo, C_), dtype=x.dtype, device=x.device)
+    idx = torch.empty((B, Ho, Wo, C_), dtype=torch.uint8, device=x.device)
+    _l.check(lib.ffa_maxpool3x3s2_fwd(_dt(x), x.data_ptr(), y.data_ptr(), idx.data_ptr(), B, H, W, C_, _stream()),
+             "maxpool_fwd")
+    return y, idx
+
+
+def maxpool3x3s2_bwd(dy: torch.Tensor, idx: torch.Tensor, in_hw: Tuple[int, int]) -> torch.Tensor:
+    lib = _l.load()
+    B, _, _, C_ = dy.shape
+    H, W = in_hw
+    dx = torch.empty((B, H, W, C_), dtype=dy.dtype, device=dy.device)
+    _l.check(lib.ffa_maxpool3x3s2_bwd(_dt(dy), dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), B, H, W, C_, _stream()),
+             "maxpool_bwd")
+    return dx
+
+
+# --------------------------------------------------------------------------------------------------
+# layout / resampling
+
+def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, cp: Optional[int] = None) -> torch.Tensor:
+    """f32 NCHW batch tensor -> NHWC compute tensor with zero-filled pad channels."""
+    lib = _l.load()
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        x = x.float().contiguous()
+    B, C_, H, W = x.shape
+    cp = cp or pad_channels(C_)
+    out = torch.empty((B, H, W, cp), dtype=dtype, device=x.device)
+    _l.check(lib.ffa_nchw_to_nhwc(_dtype_id(dtype), x.data_ptr(), out.data_ptr(), B, C_, H, W, cp, _stream()),
+             "nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor, channels: int) -> torch.Tensor:
+    lib = _l.load()
+    _chk_nhwc(x, "nhwc_to_nchw input")
+    B, H, W, cp = x.shape
+    out = torch.empty((B, channels, H, W), dtype=torch.float32, device=x.device)
+    _l.check(lib.ffa_nhwc_to_nchw(_dt(x), x.data_ptr(), out.data_ptr(), B, channels, H, W, cp, _stream()),
+             "nhwc_to_nchw")
+    return out
+
+
+def upsample2x_concat_fwd(lo: torch.Tensor, skip: Optional[torch.Tensor]) -> torch.Tensor:
+    lib = _l.load()
+    _chk_nhwc(lo, "upsample input")
+    B, Hl, Wl, C1 = lo.shape
+    C2 = 0 if skip is None else skip.shape[-1]
+    if skip is not None and tuple(skip.shape[:3]) != (B, 2 * Hl, 2 * Wl):
+        raise ValueError(f"upsample2x_concat: skip {tuple(skip.shape)} does not match 2x of {tuple(lo.shape)}")
+    out = torch.empty((B, 2 * Hl, 2 * Wl, C1 + C2), dtype=lo.dtype, device=lo.device)
+    _l.check(lib.ffa_upsample_nearest2x_concat_fwd(_dt(lo), lo.data_ptr(), _ptr(skip), out.data_ptr(), B, Hl, Wl, C1,
+                                                   C2, _stream()), "upsample2x_concat_fwd")
+    return out
+
+
+def upsample2x_concat_bwd(dcat: torch.Tensor, c1: int):
+    lib = _l.load()
+    _chk_nhwc(dcat, "upsample grad")
+    B, H, W, C_ = dcat.shape
+    c2 = C_ - c1
+    dlo = torch.empty((B, H // 2, W // 2, c1), dtype=dcat.dtype, device=dcat.device)
+    dskip = torch.empty((B, H, W, c2), dtype=dcat.dtype, device=dcat.device) if c2 else None
+    _l.check(lib.ffa_upsample_nearest2x_concat_bwd(_dt(dcat), dcat.data_ptr(), dlo.data_ptr(), _ptr(dskip), B, H // 2,
+                                                   W // 2, c1, c2, _stream()), "upsample2x_concat_bwd")
+    return dlo, dskip
+
+
+def bilinear_fwd(x: torch.Tensor, out_hw: Tuple[int, int]) -> torch.Tensor:
+    lib = _l.load()
+    _chk_nhwc(x, "bilinear input")
+    B, Hi, Wi, C_ = x.shape
+    Ho, Wo = out_hw
+    y = torch.empty((B, Ho, Wo, C_), dtype=x.dtype, device=x.device)
+    _l.check(lib.ffa_bilinear_fwd(_dt(x), x.data_ptr(), y.data_ptr(), B, Hi, Wi, Ho, Wo, C_, _stream()),
+             "bilinear_fwd")
+    return y
+
+
+def bilinear_bwd(dy: torch.Tensor, in_hw: Tuple[int, int]) -> torch.Tensor:
+    lib = _l.load()
+    _chk_nhwc(dy, "bilinear grad")
+    B, Ho, Wo, C_ = dy.shape
+    Hi, Wi = in_hw
+    dx = torch.empty((B, Hi, Wi, C_), dtype=dy.dtype, device=dy.device)
+    ws = workspace(lib.ffa_bilinear_bwd_workspace_bytes(B, Hi, Wi, C_), dy.device, "bilinear")
+    _l.check(lib.ffa_bilinear_bwd(_dt(dy), dy.data_ptr(), dx.data_ptr(), B, Hi, Wi, Ho, Wo, C_, ws.data_ptr(),
+                                  ws.numel(), _stream()), "bilinear_bwd")
+    return dx
+
+
+# --------------------------------------------------------------------------------------------------
+# loss / prediction
+
+def softmax_ce(logits: torch.Tensor, targets: torch.Tensor, class_weights: torch.Tensor, num_classes: int,
+               grad_scale: Optional[torch.Tensor] = None, want_grad: bool = False, want_pred: bool = False):
+    """Weighted-mean cross-entropy over NHWC logits [B,H,W,Cp] and uint8 targets [B,H,W].
+
+    -> (loss[1] f32, wsum[1] f32, dlogits or None, pred uint8 or None)
+    """
+    lib = _l.load()
+    _chk_nhwc(logits, "logits")
+    if targets.dtype != torch.uint8 or not targets.is_contiguous():
+        raise ValueError("softmax_ce: targets must be contiguous uint8 class indices")
+    cp = logits.shape[-1]
+    npix = logits.numel() // cp
+    if targets.numel() != npix:
+        raise ValueError("softmax_ce: target / logit pixel count mismatch")
+    dev = logits.device
+    res = torch.empty(2, dtype=torch.float32, device=dev)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    pred = torch.empty(targets.shape, dtype=torch.uint8, device=dev) if want_pred else None
+    if want_grad and grad_scale is None:
+        grad_scale = torch.ones(1, dtype=torch.float32, device=dev)
+    ws = workspace(lib.ffa_softmax_ce_workspace_bytes(), dev, "ce")
+    _l.check(lib.ffa_softmax_ce(_dt(logits), logits.data_ptr(), targets.data_ptr(), class_weights.data_ptr(),
+                                _ptr(grad_scale), res[0:1].data_ptr(), res[1:2].data_ptr(), _ptr(dlogits), _ptr(pred),
+                                npix, num_classes, cp, ws.data_ptr(), ws.numel(), _stream()), "softmax_ce")
+    return res[0:1], res[1:2], dlogits, pred
+
+
+def predict_u8(logits: torch.Tensor, num_classes: int, mode: str = "argmax", crop: Optional[Tuple[int, int, int, int]] = None
+               ) -> torch.Tensor:
+    """NHWC logits -> uint8 prediction of the cropped window (y0, x0, h, w).
+
+    'argmax' -> [B, h, w];  'class_prob' -> [B, K, h, w] = rint(softmax * 255)
+    (flair_zonal_detection/postprocess.py:9-30 semantics; unknown modes raise ValueError like the reference).
+    """
+    lib = _l.load()
+    _chk_nhwc(logits, "logits")
+    if mode not in ("argmax", "class_prob"):
+        raise ValueError(f"Unknown output type: {mode}")
+    B, H, W, cp = logits.shape
+    y0, x0, h, w = crop if crop is not None else (0, 0, H, W)
+    shape = (B, h, w) if mode == "argmax" else (B, num_classes, h, w)
+    out = torch.empty(shape, dtype=torch.uint8, device=logits.device)
+    _l.check(lib.ffa_predict_u8(_dt(logits), 0 if mode == "argmax" else 1, logits.data_ptr(), out.data_ptr(), B, H, W,
+                                num_classes, cp, y0, x0, h, w, _stream()), "predict_u8")
+    return out
+
+
+def onehot_to_index(onehot: torch.Tensor) -> torch.Tensor:
+    lib = _l.load()
+    if onehot.dtype != torch.float32 or not onehot.is_contiguous():
+        onehot = onehot.float().contiguous()
+    B, K, H, W = onehot.shape
+    out = torch.empty((B, H, W), dtype=torch.uint8, device=onehot.device)
+    _l.check(lib.ffa_onehot_to_index(onehot.data_ptr(), out.data_ptr(), B, K, H, W, _stream()), "onehot_to_index")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# host-side tile bookkeeping (no GPU involved)
+
+def slice_grid(min_x, min_y, max_x, max_y, ref_left, ref_bottom, patch_size: int, margin: int, resolution: float):
+    lib = _l.load()
+    args = (float(min_x), float(min_y), float(max_x), float(max_y), float(ref_left), float(ref_bottom),
+            int(patch_size), int(margin), float(resolution))
+    n = lib.ffa_slice_grid(*args, None, 0)
+    if n < 0:
+        _l.check(int(n), "slice_grid")
+    buf = (_l.Tile * max(n, 1))()
+    n2 = lib.ffa_slice_grid(*args, buf, n)
+    assert n2 == n
+    return [buf[i] for i in range(n)]
+
+
+def write_window(left, top, img_bounds, out_res, pred_h: int, pred_w: int):
+    lib = _l.load()
+    w = _l.Window()
+    il, ib, ir, it = img_bounds
+    _l.check(lib.ffa_write_window(float(left), float(top), float(il), float(ib), float(ir), float(it), float(out_res),
+                                  int(pred_h), int(pred_w), C.byref(w)), "write_window")
+    return w

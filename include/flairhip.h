@@ -1,0 +1,136 @@
+/* libflairhip -- C ABI of the MI355X (gfx950) tiled-segmentation hot path.
+ *
+ * The reference (kezakool/flair-for-aigle) is pure Python and has no FFI of its own: the seam this
+ * library replaces is the set of torch / segmentation_models_pytorch calls listed per entry point
+ * below (file:line under the reference tree).  INTEGRATION.md shows the ctypes binding a maintainer
+ * would add on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative FFA_ERR_* for argument / support errors, or a
+ *     positive hipError_t when a launch fails; nothing throws; ffa_last_error() gives the text of
+ *     the last failure on the calling thread
+ *   - every launch goes to the caller's hipStream_t; the library never allocates device memory,
+ *     never synchronises and keeps no mutable global state (workspace is passed in; query sizes
+ *     with the *_workspace_bytes functions)
+ *   - tensors are raw device pointers, NHWC, contiguous, dtype FFA_BF16 (storage) or FFA_F32,
+ *     channel pitch a multiple of 16 elements (8 where noted); pad channels must hold zeros
+ *   - all reductions are fixed-order (bitwise reproducible); no float atomics except
+ *     ffa_bilinear_bwd
+ */
+#ifndef FLAIRHIP_H
+#define FLAIRHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* ffa_stream_t; /* == hipStream_t */
+
+#define FFA_BF16 0
+#define FFA_F32 1
+
+#define FFA_OK 0
+#define FFA_ERR_ARG (-1)
+#define FFA_ERR_UNSUPPORTED (-2)
+#define FFA_ERR_WORKSPACE (-3)
+
+const char* ffa_last_error(void);
+int ffa_version(void);
+const char* ffa_target_arch(void);
+
+/* ---- convolution (replaces the conv2d forward/backward reached via
+ *      flair_hub/models/monotemp_model.py:68-92 -> smp encoder/decoder, called at
+ *      flair_hub/models/flair_model.py:376 and :417-419) ------------------------------------------ */
+
+/* preferred block height (output channels per workgroup) for a layer; weights are packed for it */
+int ffa_conv_block_co(int kh, int kw, int stride, int cout);
+int ffa_conv_row_group(int kh);
+long long ffa_pack_conv_weight_bytes(int dtype, int co_rows, int ci_pitch, int kh, int kw);
+/* OIHW f32 master weight -> kernel operand.  transpose=1 builds the dgrad operand (rows = input
+ * channels, taps mirrored).  scale (optional, per row) folds an eval-mode BatchNorm. */
+int ffa_pack_conv_weight(int dtype, const float* w_oihw, const float* scale, void* dst, int O, int I, int kh, int kw,
+                         int transpose, int co_rows, int ci_pitch, int bco, int rg, ffa_stream_t stream);
+/* out = relu?( conv(in, w) + bias + residual ).  dil=2 reads `in` through a virtual zero insertion
+ * (dgrad of a stride-2 layer, stride must then be 1). */
+int ffa_conv2d(int dtype, const void* in, const void* w_packed, const float* bias, const void* residual, void* out,
+               int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int co_rows, int bco, int kh, int kw, int stride,
+               int pad, int dil, int relu, ffa_stream_t stream);
+long long ffa_conv_wgrad_workspace_bytes(int dtype, int kh, int kw, int stride, int Co, int Ci, int B, int Ho, int Wo);
+int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int B, int Hi, int Wi, int Ci, int Ho,
+                   int Wo, int Co, int Co_real, int Ci_real, int kh, int kw, int stride, int pad, int accumulate,
+                   void* workspace, long long workspace_bytes, ffa_stream_t stream);
+
+/* ---- BatchNorm2d + ReLU + residual, MaxPool2d(3,2,1) (smp ResNet-34 encoder / UnetDecoder blocks;
+ *      SURVEY.md Appendix C) ----------------------------------------------------------------------- */
+long long ffa_bn_workspace_bytes(int C);
+int ffa_bn_stats(int dtype, const void* x, long long npix, int C, const float* gamma, const float* beta,
+                 float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                 float* mean_out, float* rstd_out, void* workspace, long long workspace_bytes, ffa_stream_t stream);
+int ffa_bn_eval_params(int C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, ffa_stream_t stream);
+int ffa_bn_apply(int dtype, const void* x, const void* residual, void* y, const float* scale, const float* shift,
+                 long long npix, int C, int relu, ffa_stream_t stream);
+int ffa_bn_bwd(int dtype, const void* x, const void* dy, const void* y, const float* gamma, const float* mean,
+               const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, long long npix, int C, int relu,
+               void* workspace, long long workspace_bytes, ffa_stream_t stream);
+int ffa_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int C,
+                         ffa_stream_t stream);
+int ffa_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C,
+                         ffa_stream_t stream);
+
+/* ---- layout hand-over at the model boundary (batch dict tensors are NCHW f32:
+ *      flair_hub/data/dataloader.py:105-257, flair_zonal_detection/dataset.py:174-209) -------------- */
+int ffa_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H, int W, int Cp, ffa_stream_t stream);
+int ffa_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H, int W, int Cp, ffa_stream_t stream);
+
+/* ---- decoder resampling (smp DecoderBlock nearest x2 + cat; flair_model.py:318-327 interpolate_map) */
+int ffa_upsample_nearest2x_concat_fwd(int dtype, const void* lo, const void* skip, void* out, int B, int Hl, int Wl,
+                                      int C1, int C2, ffa_stream_t stream);
+int ffa_upsample_nearest2x_concat_bwd(int dtype, const void* dcat, void* dlo, void* dskip, int B, int Hl, int Wl,
+                                      int C1, int C2, ffa_stream_t stream);
+int ffa_bilinear_fwd(int dtype, const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                     ffa_stream_t stream);
+long long ffa_bilinear_bwd_workspace_bytes(int B, int Hi, int Wi, int C);
+int ffa_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                     void* workspace, long long workspace_bytes, ffa_stream_t stream);
+
+/* ---- loss / prediction (flair_hub/tasks/module_setup.py:150-161 CrossEntropyLoss(weight);
+ *      flair_hub/tasks/tasks_module.py:153,155,158; flair_zonal_detection/inference.py:300;
+ *      flair_zonal_detection/postprocess.py:9-30) --------------------------------------------------- */
+long long ffa_softmax_ce_workspace_bytes(void);
+int ffa_softmax_ce(int dtype, const void* logits, const uint8_t* targets, const float* class_weights,
+                   const float* grad_scale, float* loss, float* wsum_out, void* dlogits, uint8_t* pred,
+                   long long npix, int K, int Cp, void* workspace, long long workspace_bytes, ffa_stream_t stream);
+int ffa_predict_u8(int dtype, int mode, const void* logits, uint8_t* out, int B, int H, int W, int K, int Cp, int y0,
+                   int x0, int h, int w, ffa_stream_t stream);
+int ffa_onehot_to_index(const float* onehot, uint8_t* idx, int B, int K, int H, int W, ffa_stream_t stream);
+
+/* ---- host-side tile bookkeeping, bit-exact with the reference's float64 arithmetic
+ *      (flair_zonal_detection/slicing.py:51-112, flair_zonal_detection/inference.py:318-335) -------- */
+typedef struct {
+  double left, bottom, right, top; /* kept area (margins removed, clipped to the zone) */
+  double x0, y0, x1, y1;           /* full tile box */
+  long long row, col;              /* id = "1-{row}-{col}" */
+} ffa_tile_t;
+/* returns the number of tiles (<= capacity written to out; call with capacity 0 to count), < 0 on error.
+ * clamp_is_pyfloat: 1 when the zone bounds are Python floats (rasterio array_bounds), which selects
+ * Python's correctly-rounded round(v, 6) for clamped coordinates in the duplicate filter. */
+long long ffa_slice_grid(double min_x, double min_y, double max_x, double max_y, double ref_left, double ref_bottom,
+                         int patch_size, int margin, double resolution, ffa_tile_t* out, long long capacity);
+typedef struct {
+  int col_off, row_off, width, height; /* rasterio Window */
+  int skip;                            /* 1 when the clipped window is empty */
+} ffa_window_t;
+int ffa_write_window(double left, double top, double img_left, double img_bottom, double img_right, double img_top,
+                     double out_res, int pred_h, int pred_w, ffa_window_t* out);
+
+/* ---- hardware layout probes (tests only) ---------------------------------------------------------- */
+int ffa_probe_tr16(const uint16_t* src, uint16_t* dst, ffa_stream_t stream);
+int ffa_probe_mfma(const float* A, const float* B, float* D, int use_f32, ffa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLAIRHIP_H */

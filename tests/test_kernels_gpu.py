@@ -1,0 +1,386 @@
+"""Per-kernel parity (GPU): every HIP kernel behind the C ABI against the torch-CPU fp32 op the
+reference reaches through segmentation_models_pytorch / torch.nn.functional.
+
+Tolerances: the f32 path must meet the north-star 1e-4 bound (scaled by the output magnitude for
+long reductions); the bf16 path is compared against the same fp32 op evaluated on bf16-rounded
+operands, with a budget of a few bf16 ulps of the output scale.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def to_nhwc(x_nchw, dtype, dev, cp=None):
+    B, C, H, W = x_nchw.shape
+    cp = cp or (C + 15) // 16 * 16
+    out = torch.zeros(B, H, W, cp, dtype=torch.float32)
+    out[..., :C] = x_nchw.permute(0, 2, 3, 1)
+    return out.to(dtype).to(dev).contiguous()
+
+
+def from_nhwc(x, C):
+    return x[..., :C].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rq(x, dtype):
+    """round through the compute dtype (identity for f32)"""
+    return x.to(dtype).float()
+
+
+def tol(dtype, ref, k_red=1):
+    scale = float(ref.abs().max()) + 1e-6
+    if dtype == torch.float32:
+        return 1e-4 * max(1.0, scale) * max(1.0, (k_red / 2000.0))
+    return scale * 2 ** -7
+
+
+# --------------------------------------------------------------------------------------------------
+
+def test_probe_mfma_layout(cuda, lib):
+    from flairhip import lib as L
+    g = torch.Generator().manual_seed(0)
+    A = torch.randint(-4, 5, (32, 16), generator=g).float()
+    Bm = torch.randint(-4, 5, (16, 32), generator=g).float()
+    for use_f32 in (0, 1):
+        D = torch.zeros(32, 32, device=cuda)
+        L.check(lib.ffa_probe_mfma(A.to(cuda).data_ptr(), Bm.to(cuda).data_ptr(), D.data_ptr(), use_f32,
+                                   torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert torch.equal(D.cpu(), A @ Bm), f"MFMA lane map assumption broken (f32={use_f32})"
+
+
+def test_probe_tr16_layout(cuda, lib):
+    from flairhip import lib as L
+    src = torch.arange(64 * 64, dtype=torch.int32).to(torch.int16)
+    dst = torch.zeros(64 * 4, dtype=torch.int16, device=cuda)
+    L.check(lib.ffa_probe_tr16(src.to(cuda).data_ptr(), dst.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    got = dst.cpu().view(64, 4).numpy()
+    s = src.view(64, 64).numpy()
+    exp = np.zeros((64, 4), dtype=np.int16)
+    for lane in range(64):
+        grp, li = lane >> 4, lane & 15
+        for e in range(4):
+            exp[lane, e] = s[4 * grp + e, 16 * grp + li]
+    assert np.array_equal(got, exp), f"ds_read_b64_tr_b16 semantics differ:\n{got[:20]}\nexpected\n{exp[:20]}"
+
+
+CONV_CASES = [
+    # (Cin, Cout, k, stride, pad, H, W, bias, res, relu)
+    (64, 64, 3, 1, 1, 16, 16, False, False, False),
+    (64, 64, 3, 1, 1, 40, 72, False, True, True),
+    (128, 128, 3, 1, 1, 32, 32, False, False, True),
+    (192, 64, 3, 1, 1, 24, 40, False, False, False),
+    (32, 16, 3, 1, 1, 64, 64, False, False, False),
+    (16, 19, 3, 1, 1, 40, 40, True, False, False),
+    (64, 128, 3, 2, 1, 32, 32, False, False, False),
+    (64, 128, 3, 2, 1, 20, 36, False, False, True),
+    (64, 128, 1, 2, 0, 32, 32, False, False, False),
+    (128, 64, 1, 1, 0, 16, 48, True, False, False),
+    (5, 64, 7, 2, 3, 64, 64, False, False, False),
+    (5, 64, 7, 2, 3, 96, 32, False, False, True),
+    (256, 512, 3, 2, 1, 8, 8, False, False, False),
+    (512, 512, 3, 1, 1, 4, 4, False, False, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{c[0]}-{c[1]}k{c[2]}s{c[3]}_{c[5]}x{c[6]}" for c in CONV_CASES])
+def test_conv_fwd(cuda, dtype, case):
+    from flairhip import ops
+    Cin, Cout, k, stride, pad, H, W, has_bias, has_res, relu = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    B = 2
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g) if has_bias else None
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Cout, Ho, Wo, generator=g) if has_res else None
+    ref = F.conv2d(rq(x, dtype), rq(w, dtype), bias, stride=stride, padding=pad)
+    if res is not None:
+        ref = ref + rq(res, dtype)
+    if relu:
+        ref = ref.relu()
+    xd = to_nhwc(x, dtype, cuda)
+    cop = (Cout + 15) // 16 * 16
+    if Cout == 19:
+        cop = 32
+    pw = ops.pack_conv_weight(w.to(cuda), dtype, stride, xd.shape[-1])
+    bd = None
+    if bias is not None:
+        bd = torch.zeros(cop, device=cuda)
+        bd[:Cout] = bias.to(cuda)
+    rd = to_nhwc(res, dtype, cuda, cop) if res is not None else None
+    out = ops.conv2d(xd, pw, pad, cop, bias=bd, residual=rd, relu=relu)
+    torch.cuda.synchronize()
+    assert out.shape == (B, Ho, Wo, cop)
+    got = from_nhwc(out, Cout)
+    err = (got - ref).abs().max().item()
+    assert err <= tol(dtype, ref, Cin * k * k), f"max err {err}"
+    if cop > Cout:  # pad channels must be exact zeros (they feed the next layer's k loop)
+        assert float(out[..., Cout:].float().abs().max()) == 0.0
+
+
+DGRAD_CASES = [
+    (64, 64, 3, 1, 1, 24, 40),
+    (128, 256, 3, 1, 1, 16, 16),
+    (64, 128, 3, 2, 1, 32, 32),
+    (64, 128, 1, 2, 0, 32, 32),
+    (16, 19, 3, 1, 1, 40, 40),
+    (32, 16, 3, 1, 1, 32, 64),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", DGRAD_CASES, ids=[f"c{c[0]}-{c[1]}k{c[2]}s{c[3]}" for c in DGRAD_CASES])
+def test_conv_dgrad(cuda, dtype, case):
+    from flairhip import ops
+    Cin, Cout, k, stride, pad, H, W = case
+    g = torch.Generator().manual_seed(1 + hash(case) % (2 ** 31))
+    B = 2
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g)
+    ref = torch.nn.grad.conv2d_input((B, Cin, H, W), rq(w, dtype), rq(dy, dtype), stride=stride, padding=pad)
+    cop = 32 if Cout == 19 else (Cout + 15) // 16 * 16
+    dyd = to_nhwc(dy, dtype, cuda, cop)
+    pw = ops.pack_conv_weight(w.to(cuda), dtype, stride, cop, transpose=True)
+    cip = (Cin + 15) // 16 * 16
+    dx = ops.conv2d(dyd, pw, k - 1 - pad, cip, dil=stride, out_hw=(H, W))
+    torch.cuda.synchronize()
+    got = from_nhwc(dx, Cin)
+    err = (got - ref).abs().max().item()
+    assert err <= tol(dtype, ref, Cout * k * k), f"max err {err}"
+
+
+WGRAD_CASES = [
+    (64, 64, 3, 1, 1, 16, 16),
+    (64, 64, 3, 1, 1, 40, 72),
+    (128, 96, 3, 1, 1, 32, 32),
+    (32, 16, 3, 1, 1, 64, 64),
+    (16, 19, 3, 1, 1, 40, 40),
+    (64, 128, 3, 2, 1, 32, 32),
+    (64, 128, 3, 2, 1, 20, 36),
+    (64, 128, 1, 2, 0, 32, 32),
+    (5, 64, 7, 2, 3, 64, 64),
+    (256, 128, 3, 1, 1, 8, 8),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[f"c{c[0]}-{c[1]}k{c[2]}s{c[3]}_{c[5]}x{c[6]}" for c in WGRAD_CASES])
+def test_conv_wgrad(cuda, dtype, case):
+    from flairhip import ops
+    Cin, Cout, k, stride, pad, H, W = case
+    g = torch.Generator().manual_seed(2 + hash(case) % (2 ** 31))
+    B = 2
+    x = torch.randn(B, Cin, H, W, generator=g)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g) / (B * Ho * Wo) ** 0.5
+    ref = torch.nn.grad.conv2d_weight(rq(x, dtype), (Cout, Cin, k, k), rq(dy, dtype), stride=stride, padding=pad)
+    cop = 32 if Cout == 19 else (Cout + 15) // 16 * 16
+    xd = to_nhwc(x, dtype, cuda)
+    dyd = to_nhwc(dy, dtype, cuda, cop)
+    dw = ops.conv_wgrad(xd, dyd, Cout, Cin, k, k, stride, pad)
+    torch.cuda.synchronize()
+    err = (dw.cpu() - ref).abs().max().item()
+    assert dw.shape == ref.shape
+    assert err <= tol(dtype, ref, B * Ho * Wo), f"max err {err}"
+    # accumulate=True adds onto the existing gradient
+    dw2 = ops.conv_wgrad(xd, dyd, Cout, Cin, k, k, stride, pad, out=dw.clone(), accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.allclose(dw2, 2 * dw, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("C,H,W,relu,res", [(64, 24, 40, True, False), (16, 64, 64, True, False),
+                                            (512, 4, 4, True, True), (128, 16, 16, False, False),
+                                            (256, 8, 24, True, True)])
+def test_batchnorm_train(cuda, dtype, C, H, W, relu, res):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(C + H)
+    B = 3
+    x = (torch.randn(B, C, H, W, generator=g) * 1.7 + 0.3)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.1
+    r = torch.randn(B, C, H, W, generator=g) if res else None
+    dy = torch.randn(B, C, H, W, generator=g)
+    rm, rv = torch.zeros(C), torch.ones(C)
+
+    xq = rq(x, dtype).requires_grad_(True)
+    gq = gamma.clone().requires_grad_(True)
+    bq = beta.clone().requires_grad_(True)
+    rq_ = rq(r, dtype).requires_grad_(True) if res else None
+    y_ref = F.batch_norm(xq, rm, rv, gq, bq, training=True, momentum=0.1, eps=1e-5)
+    if res:
+        y_ref = y_ref + rq_
+    if relu:
+        y_ref = y_ref.relu()
+
+    xd = to_nhwc(x, dtype, cuda)
+    rmd, rvd = torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
+    scale, shift, mean, rstd = ops.bn_stats(xd, gamma.to(cuda), beta.to(cuda), rmd, rvd, 0.1, 1e-5)
+    rd = to_nhwc(r, dtype, cuda) if res else None
+    y = ops.bn_apply(xd, scale, shift, residual=rd, relu=relu)
+    torch.cuda.synchronize()
+    assert (from_nhwc(y, C) - y_ref.detach()).abs().max().item() <= tol(dtype, y_ref.detach()) * 4
+    assert torch.allclose(rmd.cpu(), rm, atol=1e-5, rtol=1e-5)  # F.batch_norm updated rm/rv in place
+    assert torch.allclose(rvd.cpu(), rv, atol=1e-5, rtol=1e-4)
+
+    # backward uses the module's own forward output for the ReLU mask, as the product path does
+    y_back = from_nhwc(y, C)
+    mask = (y_back > 0).float() if relu else torch.ones_like(y_back)
+    y_ref2 = F.batch_norm(xq, None, None, gq, bq, training=True, eps=1e-5)
+    (y_ref2 * (rq(dy, dtype) * mask)).sum().backward()
+    dyd = to_nhwc(dy, dtype, cuda)
+    dx, dres, dgamma, dbeta = ops.bn_bwd(xd, dyd, y, gamma.to(cuda), mean, rstd, relu, res)
+    torch.cuda.synchronize()
+    assert (from_nhwc(dx, C) - xq.grad).abs().max().item() <= tol(dtype, xq.grad) * 4
+    n = B * H * W
+    assert (dgamma.cpu() - gq.grad).abs().max().item() <= (1e-3 if dtype == torch.float32 else 0.05) * n ** 0.5
+    assert (dbeta.cpu() - bq.grad).abs().max().item() <= (1e-3 if dtype == torch.float32 else 0.05) * n ** 0.5
+    if res:
+        exp = rq(dy, dtype) * mask
+        assert (from_nhwc(dres, C) - exp).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_bn_eval_params(cuda, dtype):
+    from flairhip import ops
+    C = 64
+    g = torch.Generator().manual_seed(5)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.2
+    scale, shift = ops.bn_eval_params(gamma.to(cuda), beta.to(cuda), rm.to(cuda), rv.to(cuda), 1e-5)
+    s_ref = gamma / torch.sqrt(rv + 1e-5)
+    assert torch.allclose(scale.cpu(), s_ref, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(shift.cpu(), beta - rm * s_ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("H,W", [(32, 32), (22, 38)])
+def test_maxpool(cuda, dtype, H, W):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(H)
+    B, C = 2, 64
+    x = torch.randn(B, C, H, W, generator=g).relu()  # many exact-zero ties, like the stem's ReLU output
+    xq = rq(x, dtype).requires_grad_(True)
+    y_ref = F.max_pool2d(xq, 3, 2, 1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(rq(dy, dtype))
+    xd = to_nhwc(x, dtype, cuda)
+    y, idx = ops.maxpool3x3s2_fwd(xd)
+    dx = ops.maxpool3x3s2_bwd(to_nhwc(dy, dtype, cuda), idx, (H, W))
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(y, C), y_ref.detach())
+    err = (from_nhwc(dx, C) - xq.grad).abs().max().item()
+    assert err <= (1e-6 if dtype == torch.float32 else 0.02), f"maxpool bwd routes ties differently: {err}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_layout_roundtrip(cuda, dtype):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 5, 24, 40, generator=g)
+    xd = ops.nchw_to_nhwc(x.to(cuda), dtype)
+    assert xd.shape == (2, 24, 40, 16)
+    assert float(xd[..., 5:].float().abs().max()) == 0.0
+    back = ops.nhwc_to_nchw(xd, 5)
+    torch.cuda.synchronize()
+    assert torch.equal(back.cpu(), rq(x, dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("C1,C2", [(64, 64), (32, 0), (512, 256)])
+def test_upsample_concat(cuda, dtype, C1, C2):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(C1)
+    B, Hl, Wl = 2, 6, 10
+    lo = torch.randn(B, C1, Hl, Wl, generator=g)
+    skip = torch.randn(B, C2, 2 * Hl, 2 * Wl, generator=g) if C2 else None
+    loq = rq(lo, dtype).requires_grad_(True)
+    parts = [F.interpolate(loq, scale_factor=2, mode="nearest")]
+    if C2:
+        skq = rq(skip, dtype).requires_grad_(True)
+        parts.append(skq)
+    ref = torch.cat(parts, 1)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(rq(dy, dtype))
+    out = ops.upsample2x_concat_fwd(to_nhwc(lo, dtype, cuda), to_nhwc(skip, dtype, cuda) if C2 else None)
+    dlo, dsk = ops.upsample2x_concat_bwd(to_nhwc(dy, dtype, cuda), C1)
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(out, C1 + C2), ref.detach())
+    assert (from_nhwc(dlo, C1) - loq.grad).abs().max().item() <= (1e-5 if dtype == torch.float32 else 0.05)
+    if C2:
+        assert torch.equal(from_nhwc(dsk, C2), skq.grad)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("hi,wi,ho,wo", [(16, 16, 64, 64), (24, 40, 24, 40), (13, 9, 40, 31), (32, 32, 10, 12)])
+def test_bilinear(cuda, dtype, hi, wi, ho, wo):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(hi * wo)
+    B, C = 2, 32
+    x = torch.randn(B, C, hi, wi, generator=g)
+    xq = rq(x, dtype).requires_grad_(True)
+    ref = F.interpolate(xq, size=(ho, wo), mode="bilinear", align_corners=False)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(rq(dy, dtype))
+    y = ops.bilinear_fwd(to_nhwc(x, dtype, cuda), (ho, wo))
+    dx = ops.bilinear_bwd(to_nhwc(dy, dtype, cuda), (hi, wi))
+    torch.cuda.synchronize()
+    assert (from_nhwc(y, C) - ref.detach()).abs().max().item() <= (2e-6 if dtype == torch.float32 else 0.04)
+    assert (from_nhwc(dx, C) - xq.grad).abs().max().item() <= (2e-5 if dtype == torch.float32 else 0.1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_softmax_ce_and_predictions(cuda, dtype):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(11)
+    B, K, H, W = 2, 19, 40, 56
+    z = torch.randn(B, K, H, W, generator=g) * 3
+    z[0, :, 0, 0] = 1.25  # exact ties -> lowest index must win
+    t = torch.randint(0, K, (B, H, W), generator=g)
+    wts = torch.tensor([1.0] * 15 + [0.0] * 4)
+    zq = rq(z, dtype).requires_grad_(True)
+    loss_ref = F.cross_entropy(zq, t, weight=wts)
+    loss_ref.backward()
+    pred_ref = torch.argmax(torch.softmax(zq.detach(), 1), 1)
+    zd = to_nhwc(z, dtype, cuda, 32)
+    zd[..., K:] = 7.0  # garbage in the pad channels must be ignored
+    td = t.to(torch.uint8).to(cuda)
+    loss, wsum, dz, pred = ops.softmax_ce(zd, td, wts.to(cuda), K, want_grad=True, want_pred=True)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) <= 2e-5 * max(1.0, abs(loss_ref.item()))
+    assert abs(wsum.item() - float(wts[t].sum())) < 1e-3
+    gtol = 1e-9 if dtype == torch.float32 else 2 ** -8 * float(zq.grad.abs().max())
+    assert (from_nhwc(dz, K) - zq.grad).abs().max().item() <= max(gtol, 1e-9)
+    assert float(dz[..., K:].float().abs().max()) == 0.0
+    assert torch.equal(pred.cpu().long(), pred_ref)
+    # zonal conversion: margin crop + argmax / class_prob (postprocess.convert semantics)
+    m = 4
+    am = ops.predict_u8(zd, K, "argmax", (m, m, H - 2 * m, W - 2 * m))
+    cp = ops.predict_u8(zd, K, "class_prob", (m, m, H - 2 * m, W - 2 * m))
+    torch.cuda.synchronize()
+    zc = zq.detach()[:, :, m:H - m, m:W - m]
+    assert torch.equal(am.cpu().long(), zc.argmax(1))
+    cp_ref = np.round(torch.softmax(zc.double(), 1).numpy() * 255).astype(np.uint8)
+    diff = np.abs(cp.cpu().numpy().astype(int) - cp_ref.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3  # f32 vs f64 softmax differ only at .5 ties
+    with pytest.raises(ValueError):
+        ops.predict_u8(zd, K, "logits")
+
+
+def test_onehot_to_index(cuda):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(2)
+    t = torch.randint(0, 19, (2, 33, 47), generator=g)
+    oh = F.one_hot(t, 19).permute(0, 3, 1, 2).float().contiguous()
+    idx = ops.onehot_to_index(oh.to(cuda))
+    torch.cuda.synchronize()
+    assert torch.equal(idx.cpu().long(), t)
