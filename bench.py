@@ -1,0 +1,254 @@
+#!/usr/bin/env python
+"""Headline benchmark: 512x512x5 tiles/sec, training step (fwd + bwd + AdamW) of the 19-class U-Net
+(ResNet-34 encoder) on synthetic tiles, data-parallel over N MI355X (BASELINE.json).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of 32 tiles per GPU (weak scaling): NCHW f32 batch ->
+NHWC bf16, encoder / decoder conv stack (HIP implicit-GEMM on MFMA), BN / pool / upsample kernels, fused
+softmax-CE (+argmax), full backward, gradient mean over ranks (RCCL, overlapped), AdamW + OneCycleLR.
+Inputs are generated on the device before the timed region (random, never zeros: DVFS).
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- the dominant kernel symbol of the step, timed live with HIP events on the stream the
+                  kernels run on: achieved = algorithmic FLOPs of its launches / their summed duration
+  cpu_baseline -- the oracle (torch-CPU fp32 restatement of the same step, kind "port") timed on this
+                  box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "flair-for-aigle_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch
+import torch.distributed as dist
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3
+TASK = "AERIAL_LABEL-COSIA"
+MOD = "AERIAL_RGBI"
+
+
+class KernelTimer:
+    """HIP-event timing of the MFMA kernels, keyed by kernel symbol (template instantiation)."""
+
+    def __init__(self):
+        self.records = []  # (symbol, flops, start, end)
+        self.enabled = False
+
+    def install(self):
+        from flairhip import ops
+        timer = self
+        orig_conv, orig_wgrad = ops.conv2d, ops.conv_wgrad
+
+        def conv2d(x, w, pad, out_channels, *a, **kw):
+            if not timer.enabled:
+                return orig_conv(x, w, pad, out_channels, *a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = orig_conv(x, w, pad, out_channels, *a, **kw)
+            e.record()
+            dil = kw.get("dil", 1)
+            B, Ho, Wo = y.shape[0], y.shape[1], y.shape[2]
+            flops = 2.0 * B * (Ho * Wo / (dil * dil)) * w.rows_real * w.ch_real * w.kh * w.kw
+            tile = "8x32" if Wo >= 32 else "16x16"
+            dt = "bf16" if x.dtype == torch.bfloat16 else "f32"
+            sym = f"conv_igemm_kernel<{dt},{w.kh}x{w.kw},s{w.stride},bco{w.bco},{tile}>"
+            timer.records.append((sym, flops, s, e))
+            return y
+
+        def conv_wgrad(x, dy, co_real, ci_real, kh, kw_, stride, pad, *a, **kw):
+            if not timer.enabled:
+                return orig_wgrad(x, dy, co_real, ci_real, kh, kw_, stride, pad, *a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_wgrad(x, dy, co_real, ci_real, kh, kw_, stride, pad, *a, **kw)
+            e.record()
+            B, Ho, Wo = dy.shape[0], dy.shape[1], dy.shape[2]
+            flops = 2.0 * B * Ho * Wo * co_real * ci_real * kh * kw_
+            dt = "bf16" if x.dtype == torch.bfloat16 else "f32"
+            wco = 2 if (dy.shape[-1] > 32 or not (kh == 3 and stride == 1)) else 1
+            wci = 2 if (x.shape[-1] > 32 and dt == "bf16") else 1
+            sym = f"conv_wgrad_kernel<{dt},{kh}x{kw_},s{stride},w{wco}x{wci}>+reduce"
+            timer.records.append((sym, flops, s, e))
+            return r
+
+        ops.conv2d, ops.conv_wgrad = conv2d, conv_wgrad
+
+    def summary(self):
+        agg = defaultdict(lambda: [0.0, 0.0, 0])
+        for sym, flops, s, e in self.records:
+            a = agg[sym]
+            a[0] += flops
+            a[1] += s.elapsed_time(e) * 1e-3
+            a[2] += 1
+        return {k: {"flops": v[0], "seconds": v[1], "launches": v[2]} for k, v in agg.items()}
+
+
+def cpu_baseline(budget_s: float = 25.0):
+    """The oracle's training step on the host cores (fp32, NCHW, eager, AdamW): B=2 tiles per step."""
+    import torch.nn.functional as F
+    from oracle.unet_resnet34 import UnetResNet34
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    torch.manual_seed(2025)
+    model = UnetResNet34(5, 19).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-5, weight_decay=0.01, betas=(0.9, 0.999))
+    B = 2
+    x = torch.randn(B, 5, 512, 512)
+    t = torch.randint(0, 19, (B, 512, 512))
+    w = torch.tensor([1.0] * 15 + [0.0] * 4)
+
+    def step():
+        loss = F.cross_entropy(model(x), t, weight=w)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+
+    t0 = time.perf_counter()
+    step()  # warm-up
+    warm = time.perf_counter() - t0
+    n = max(1, min(4, int(budget_s / max(warm, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    dt = time.perf_counter() - t0
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": round(B * n / dt, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
+            "sample": f"{n} timed step(s) of batch {B} (512x512x5, 19 classes, fp32 NCHW eager, AdamW) after 1 warm-up; "
+                      f"oracle/unet_resnet34.py on '{cpu_model}'"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="tiles per GPU per step")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--tile", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-symbol table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from flairhip.configs import unet_resnet34_config
+    from flairhip.distributed import GradSync
+    from flair_hub.tasks.module_setup import build_segmentation_module
+
+    total_steps = args.steps + args.warmup
+    cfg = unet_resnet34_config(in_channels=5, precision=args.precision, batch_size=args.batch,
+                               total_steps=max(total_steps, 10))
+    torch.manual_seed(cfg["hyperparams"]["seed"])
+    task = build_segmentation_module(cfg, {MOD: args.tile}, "train").to(dev)
+    task.train()
+    opt_cfg = task.configure_optimizers()
+    optimizer, scheduler = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
+    sync = GradSync(task.model)
+
+    g = torch.Generator(device=dev).manual_seed(2025 + rank)
+    B, S = args.batch, args.tile
+    x = torch.randn(B, 5, S, S, generator=g, device=dev)
+    t = torch.randint(0, 19, (B, S, S), generator=g, device=dev, dtype=torch.uint8)
+    batch = {MOD: x, TASK: t}
+
+    timer = KernelTimer()
+    timer.install()
+
+    def step(i):
+        loss = task.training_step(batch, i)
+        optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        sync.finish()
+        optimizer.step()
+        scheduler.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    final_loss = float(loss.item())
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        tiles_per_s = world * B * args.steps / elapsed
+        summ = timer.summary()
+        dom = max(summ.items(), key=lambda kv: kv[1]["seconds"])
+        peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
+        ach = dom[1]["flops"] / dom[1]["seconds"] / 1e12
+        mfma_total = sum(v["seconds"] for v in summ.values())
+        roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None,
+                    "launches_per_step": dom[1]["launches"] / args.steps,
+                    "avg_launch_ms": round(dom[1]["seconds"] / dom[1]["launches"] * 1e3, 4),
+                    "mfma_kernels_share_of_step": round(mfma_total / elapsed, 4)}
+        if args.breakdown:
+            for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"]):
+                print(f"  {k:62s} {v['seconds'] / args.steps * 1e3:8.3f} ms/step {v['launches'] // args.steps:4d} launches "
+                      f"{v['flops'] / v['seconds'] / 1e12:8.1f} TFLOP/s", file=sys.stderr)
+            print(f"  MFMA kernels total {mfma_total / args.steps * 1e3:.3f} ms of {ms:.3f} ms/step; loss {final_loss:.4f}",
+                  file=sys.stderr)
+        out = {
+            "metric": "512x512x5 tiles/sec (train fwd+bwd+AdamW), U-Net ResNet-34, 19 classes",
+            "value": round(tiles_per_s, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"synthetic {S}x{S}x5 tiles, 19-class U-Net (ResNet-34 encoder), batch {B} per GPU, "
+                                   f"train step (BASELINE.json configs[{1 if world == 1 else 2}])",
+                       "global_batch": B * world, "tile": S, "parallelism": f"dp{world}"},
+            "final_loss": round(final_loss, 5),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

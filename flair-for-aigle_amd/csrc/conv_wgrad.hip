@@ -243,7 +243,7 @@ static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, in
   p->rg = stem ? 1 : kh;
   p->tw = (Wo >= 32) ? 32 : 16;
   p->th = (Wo >= 32) ? 8 : 16;
-  if (s2 || stem) {  // halo of a stride-2 tile is 4x larger: halve the tile
+  if (!s1) {  // stride-2 halos are 4x larger and only the 8x16 tile is instantiated for these shapes
     p->tw = 16;
     p->th = 8;
   }

@@ -494,3 +494,27 @@ extern "C" int ffa_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* id
                        (const float*)dy, idx, (float*)dx, B, H, W, C, Ho, Wo);
   return ffa_check_launch("maxpool_bwd");
 }
+
+// Per-channel sum and sum of squares of x[N][C] (f32 outputs); used for the head-conv bias gradient.
+extern "C" int ffa_channel_sums(int dtype, const void* x, long long npix, int C, float* sum_out, float* sumsq_out,
+                                void* workspace, long long workspace_bytes, hipStream_t stream) {
+  FFA_REQUIRE(x && sum_out && sumsq_out && workspace, "channel_sums: null pointer");
+  FFA_REQUIRE(C % 8 == 0 && C >= 8 && C <= 8 * FFA_EW_THREADS, "channel_sums: unsupported channel count %d", C);
+  if (workspace_bytes < ffa_bn_workspace_bytes(C)) {
+    ffa_set_error("channel_sums: workspace too small");
+    return FFA_ERR_WORKSPACE;
+  }
+  const int nb = reduce_blocks(npix, C);
+  float* ws = static_cast<float*>(workspace);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL((channel_reduce_kernel<ffa_bf16, StatOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
+                       (const ffa_bf16*)x, (const ffa_bf16*)nullptr, (const ffa_bf16*)nullptr, nullptr, nullptr, ws,
+                       npix, C, 0);
+  else
+    hipLaunchKernelGGL((channel_reduce_kernel<float, StatOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
+                       (const float*)x, (const float*)nullptr, (const float*)nullptr, nullptr, nullptr, ws, npix, C, 0);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ffa_cdiv(C, 128)), dim3(128), 0, stream, ws, nb, C, sumsq_out,
+                     sum_out);
+  return ffa_check_launch("channel_sums");
+}
+

@@ -1,0 +1,170 @@
+"""FLAIR_HUB_Model on libflairhip -- drop-in for the reference's flair_hub/models/flair_model.py
+(class FLAIR_HUB_Model :16, forward :357-430, interpolate_map :318-327, FusionHandler :437-547).
+
+Same constructor, attributes (``encoders``, ``fusion_handler``, ``main_decoders``, ``aux_decoders``,
+``task_nclasses``, ``config``) and ``forward(batch, apply_mod_dropout=False) -> (logits_tasks,
+logits_aux)`` contract.  Inside, tensors are NHWC in the compute dtype (``config['hardware']
+['precision']``: 'bf16' default, 'fp32' for the 1e-4 parity mode) and every operator is a HIP kernel.
+
+Scope of this round: one mono-temporal modality, one or several tasks.  Multi-modal
+fusion and the Sentinel U-TAE branch raise NotImplementedError naming what is missing.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+
+from flairhip import nn as hnn
+from flairhip import ops
+from flair_hub.models.monotemp_model import FLAIR_Monotemp
+
+logger = logging.getLogger(__name__)
+
+MONO_KEYS = ["AERIAL_RGBI", "AERIAL-RLT_PAN", "DEM_ELEV", "SPOT_RGBI"]
+MULTI_KEYS = ["SENTINEL2_TS", "SENTINEL1-ASC_TS", "SENTINEL1-DESC_TS"]
+
+
+def compute_dtype_of(config: dict) -> torch.dtype:
+    name = str(config.get("hardware", {}).get("precision", "bf16")).lower()
+    if name in ("bf16", "bfloat16", "bf16-mixed"):
+        return torch.bfloat16
+    if name in ("fp32", "32", "float32", "32-true"):
+        return torch.float32
+    raise ValueError(f"unsupported hardware.precision '{name}' (use 'bf16' or 'fp32')")
+
+
+class FusionHandler(nn.Module):
+    """Feature fusion across modalities (reference :437-547).  With a single mono-temporal modality the
+    reference returns that modality's feature list untouched (:489-490) -- the only case wired up so far;
+    the per-stage 1x1 ``conv_f`` parameters are still created so state dicts keep their keys."""
+
+    def __init__(self, backbones_channels: List[int], target_fused_channels: List[int], mono_keys: List[str],
+                 multi_keys: List[str]) -> None:
+        super().__init__()
+        self.mono_keys, self.multi_keys = mono_keys, multi_keys
+        target = list(target_fused_channels)
+        if len(target) > 2 and (target[0] == 0 or target[1] == 0):
+            target = target[2:]
+        self.conv_f = nn.ModuleList(
+            hnn.HipConv2d(cin, cout, 1, 1, 0, bias=True) for cin, cout in zip(backbones_channels, target))
+
+    def forward(self, feature_maps: dict, target_fm_maps):
+        active = list(feature_maps.keys())
+        mono = [k for k in active if k in self.mono_keys]
+        multi = [k for k in active if k in self.multi_keys]
+        if len(mono) == 1 and not multi:
+            return feature_maps[mono[0]]
+        if not mono and len(multi) == 1:
+            return feature_maps[multi[0]]
+        raise NotImplementedError(
+            f"feature fusion over modalities {active} is not implemented on libflairhip yet "
+            "(SURVEY.md section 8f rank 1: bilinear align + concat + per-stage 1x1 conv)")
+
+
+class FLAIR_HUB_Model(nn.Module):
+    def __init__(self, config: dict, img_input_sizes: dict):
+        super().__init__()
+        self.config = config
+        self.img_input_sizes = img_input_sizes
+        self.mono_keys = list(MONO_KEYS)
+        self.multi_keys = list(MULTI_KEYS)
+        self.compute_dtype = compute_dtype_of(config)
+
+        mods = config["modalities"]
+        inputs = mods["inputs"]
+        self.aux_losses = {m: v for m, v in mods.get("aux_loss", {}).items() if v and inputs.get(m, False)}
+        self.tasks = len(config["labels"])
+        self.task_nclasses = sum(len(config["labels_configs"][t]["value_name"]) for t in config["labels"])
+
+        # channel count per modality (reference :70-87)
+        self.channels_dict = {}
+        for m in inputs:
+            if m in ("AERIAL-RLT_PAN", "DEM_ELEV"):
+                self.channels_dict[m] = 1
+            else:
+                self.channels_dict[m] = len(mods["inputs_channels"][m]) if m in mods.get("inputs_channels", {}) else 0
+        if inputs.get("DEM_ELEV", False):
+            pp = mods["pre_processings"]
+            self.channels_dict["DEM_ELEV"] = 1 if (pp["calc_elevation"] and not pp["calc_elevation_stack_dsm"]) else 2
+
+        if any(inputs.get(k, False) for k in self.multi_keys):
+            raise NotImplementedError("Sentinel time-series (U-TAE) branch is not implemented on libflairhip yet "
+                                      "(SURVEY.md section 8f rank 3)")
+        if self.aux_losses:
+            raise NotImplementedError("auxiliary decoders are not implemented on libflairhip yet")
+
+        self.encoders = nn.ModuleDict()
+        for m in self.mono_keys:
+            if inputs.get(m, False):
+                self.encoders[m] = FLAIR_Monotemp(config, channels=self.channels_dict[m], classes=self.task_nclasses,
+                                                  img_size=img_input_sizes[m], return_type="encoder")
+        if not self.encoders:
+            raise ValueError("no active input modality in config['modalities']['inputs']")
+
+        per_stage = [list(self.encoders[m].seg_model.out_channels) for m in self.encoders]
+        total_per_stage = [sum(c) for c in zip(*per_stage)]
+        target = next(iter(self.encoders.values())).seg_model.out_channels
+        self.fusion_handler = FusionHandler(total_per_stage, target, self.mono_keys, self.multi_keys)
+
+        self.main_decoders = nn.ModuleDict()
+        for task in config["labels"]:
+            self.main_decoders[task] = FLAIR_Monotemp(
+                config, channels=1, classes=len(config["labels_configs"][task]["value_name"]), return_type="decoder")
+        self.aux_decoders = nn.ModuleDict()
+        self._log_parameter_table()
+
+    # ---- helpers ---------------------------------------------------------------------------------
+
+    def _log_parameter_table(self) -> None:
+        arch = self.config["models"]["monotemp_model"]["arch"]
+        total = 0
+        for kind, group in (("backbone", self.encoders), ("task decoder", self.main_decoders)):
+            for key, mod in group.items():
+                n = sum(p.numel() for p in mod.parameters())
+                total += n
+                logger.info("| %-30s | %-28s | %-14s | %13s |", key, arch, kind, f"{n:,}")
+        logger.info("| %-30s   %-28s   %-14s   %13s |", "Total parameters", "", "", f"{total:,}")
+
+    def interpolate_map(self, x: torch.Tensor, size) -> torch.Tensor:
+        """bilinear, align_corners=False (reference :318-327); ``size`` may be an int as in the reference's call."""
+        hw = (size, size) if isinstance(size, int) else tuple(size)
+        return hnn.bilinear(x, hw)
+
+    def _input_nhwc(self, x: torch.Tensor, mod: str) -> torch.Tensor:
+        enc = self.encoders[mod].seg_model
+        if x.ndim != 4 or x.shape[1] != enc.in_channels:
+            raise ValueError(f"batch['{mod}'] must be [B,{enc.in_channels},H,W], got {tuple(x.shape)}")
+        if x.shape[-1] % 32 or x.shape[-2] % 32:
+            raise RuntimeError(f"input height and width must be divisible by 32, got {tuple(x.shape[-2:])}")
+        if not x.is_cuda:
+            raise RuntimeError("FLAIR_HUB_Model (libflairhip) runs on an MI355X only: move the batch to cuda")
+        return hnn.to_nhwc(x, self.compute_dtype, ops.pad_channels(enc.in_channels))
+
+    # ---- forward ---------------------------------------------------------------------------------
+
+    def forward(self, batch: dict, apply_mod_dropout: bool = False) -> Tuple[Dict[str, torch.Tensor], Dict]:
+        labels = self.config["labels"]
+        fmaps: Dict[str, list] = {}
+        first_mod = next(iter(self.encoders))
+        # the reference learns the output size from the label tensor (:371); the zonal dataset fabricates a
+        # zero label for that purpose -- fall back to the input size when no label rides along
+        # (the reference passes the int shape[-1], i.e. assumes square tiles; both dims are kept here, which is
+        # the same thing for the square tiles it is used with)
+        if labels and labels[0] in batch:
+            img_size = tuple(batch[labels[0]].shape[-2:])
+        else:
+            img_size = tuple(batch[first_mod].shape[-2:])
+
+        for mod, encoder in self.encoders.items():
+            fmaps[mod] = encoder.seg_model(self._input_nhwc(batch[mod], mod))
+        fused = self.fusion_handler(fmaps, fmaps[first_mod])
+
+        logits_tasks: Dict[str, torch.Tensor] = {}
+        for task in labels:
+            y = self.main_decoders[task].seg_model(*fused)
+            y = self.interpolate_map(y, img_size)
+            logits_tasks[task] = hnn.logits_view(y, len(self.config["labels_configs"][task]["value_name"]))
+        return logits_tasks, {}

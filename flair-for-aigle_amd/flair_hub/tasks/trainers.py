@@ -1,0 +1,173 @@
+"""Training / prediction drivers -- counterpart of the reference's flair_hub/tasks/trainers.py
+(train :35-108 builds a pytorch_lightning.Trainer and calls fit/validate; predict :111-136).
+
+Lightning is replaced by HipTrainer: one process per GPU, the SegmentationTask hooks are called in
+Lightning's order, gradients are averaged across ranks by flairhip.distributed.GradSync (RCCL over
+xGMI, overlapped with backward) in place of Lightning's DDP strategy.  Callbacks, loggers and
+checkpoint policies of the reference are orchestration outside the hot path; what is kept is the
+best-checkpoint-on-val_miou save so that stages can reload it.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Any, Dict, Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+from flairhip.distributed import GradSync
+
+logger = logging.getLogger(__name__)
+
+
+def check_batchnorm_and_batch_size(config: Dict[str, Any], seg_module: torch.nn.Module) -> None:
+    """Abort on BatchNorm with batch size 1 (reference :17-32): batch statistics of one sample are degenerate."""
+    from flairhip.nn import HipBatchNorm2d
+    if config["hyperparams"]["batch_size"] == 1 and any(isinstance(m, HipBatchNorm2d) for m in seg_module.modules()):
+        raise SystemExit("BatchNorm layers need a batch size > 1 for training")
+
+
+def _to_device(batch: dict, device) -> dict:
+    return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+class HipTrainer:
+    """The subset of pytorch_lightning.Trainer the reference relies on."""
+
+    def __init__(self, accelerator: str = "gpu", devices: int = 1, strategy: str = "auto", num_nodes: int = 1,
+                 max_epochs: int = 1, default_root_dir: Optional[str] = None, monitor: str = "val_miou",
+                 monitor_mode: str = "max", max_steps: Optional[int] = None, **unused):
+        if accelerator not in ("gpu", "cuda", "auto"):
+            raise RuntimeError("HipTrainer drives the MI355X path only (accelerator='gpu'); the CPU restatement "
+                               "lives in oracle/ and is test infrastructure")
+        self.max_epochs, self.max_steps = max_epochs, max_steps
+        self.default_root_dir = default_root_dir
+        self.monitor, self.monitor_mode = monitor, monitor_mode
+        self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = torch.device("cuda", local)
+        self.estimated_stepping_batches = 0
+        self.callback_metrics: Dict[str, Any] = {}
+        self.best_model_path = None
+        self.optimizers = []
+
+    # ---- fit -------------------------------------------------------------------------------------
+
+    def fit(self, model, datamodule=None, train_dataloaders: Optional[Iterable] = None,
+            val_dataloaders: Optional[Iterable] = None) -> None:
+        torch.cuda.set_device(self.device)
+        model.to(self.device)
+        model.trainer = self
+        if datamodule is not None:
+            datamodule.setup("fit")
+            train_dataloaders = datamodule.train_dataloader()
+            val_dataloaders = datamodule.val_dataloader() if hasattr(datamodule, "val_dataloader") else None
+        steps_per_epoch = len(train_dataloaders)
+        self.estimated_stepping_batches = self.max_steps or steps_per_epoch * self.max_epochs
+
+        opt_cfg = model.configure_optimizers()
+        optimizer = opt_cfg["optimizer"] if isinstance(opt_cfg, dict) else opt_cfg
+        sched_cfg = opt_cfg.get("lr_scheduler") if isinstance(opt_cfg, dict) else None
+        scheduler = sched_cfg["scheduler"] if sched_cfg else None
+        interval = sched_cfg.get("interval", "epoch") if sched_cfg else None
+        model._lr_scheduler = scheduler
+        self.optimizers = [optimizer]
+        sync = GradSync(model)
+
+        best = None
+        done = False
+        for epoch in range(self.max_epochs):
+            model.train()
+            for i, batch in enumerate(train_dataloaders):
+                batch = _to_device(batch, self.device)
+                loss = model.training_step(batch, i)
+                optimizer.zero_grad(set_to_none=True)
+                loss.backward()
+                sync.finish()
+                optimizer.step()
+                if scheduler is not None and interval == "step":
+                    scheduler.step()
+                model.global_step += 1
+                model.on_train_batch_end(loss, batch, i)
+                if self.max_steps and model.global_step >= self.max_steps:
+                    done = True
+                    break
+            model.on_train_epoch_end()
+            if val_dataloaders is not None:
+                self.validate(model, dataloaders=val_dataloaders)
+                score = self.callback_metrics.get(self.monitor)
+                if score is not None:
+                    score = float(score)
+                    better = best is None or (score > best if self.monitor_mode == "max" else score < best)
+                    if better:
+                        best = score
+                        self._save_best(model, epoch, score)
+                if scheduler is not None and interval == "epoch":
+                    monitor = sched_cfg.get("monitor")
+                    scheduler.step(self.callback_metrics[monitor]) if monitor else scheduler.step()
+            if done:
+                break
+        sync.remove()
+
+    def _save_best(self, model, epoch: int, score: float) -> None:
+        if self.rank != 0 or not self.default_root_dir:
+            return
+        os.makedirs(self.default_root_dir, exist_ok=True)
+        path = os.path.join(self.default_root_dir, f"ckpt-epoch={epoch:02d}-{self.monitor}={score:.2f}.ckpt")
+        torch.save({"state_dict": model.state_dict(), "epoch": epoch}, path)
+        self.best_model_path = path
+
+    # ---- validate / predict ----------------------------------------------------------------------
+
+    @torch.no_grad()
+    def validate(self, model, datamodule=None, dataloaders: Optional[Iterable] = None):
+        model.to(self.device)
+        model.trainer = self
+        if datamodule is not None:
+            datamodule.setup("validate")
+            dataloaders = datamodule.val_dataloader()
+        model.eval()
+        for i, batch in enumerate(dataloaders):
+            model.validation_step(_to_device(batch, self.device), i)
+        model.on_validation_epoch_end()
+        self.callback_metrics.update({k: (float(v) if torch.is_tensor(v) else v) for k, v in model._logged.items()})
+        return [dict(self.callback_metrics)]
+
+    @torch.no_grad()
+    def predict(self, model, datamodule=None, dataloaders: Optional[Iterable] = None, return_predictions: bool = True):
+        model.to(self.device)
+        model.trainer = self
+        if datamodule is not None:
+            datamodule.setup("predict")
+            dataloaders = datamodule.predict_dataloader()
+        model.eval()
+        outs = []
+        for i, batch in enumerate(dataloaders):
+            out = model.predict_step(_to_device(batch, self.device), i)
+            if return_predictions:
+                outs.append(out)
+        return outs
+
+
+def train(config: Dict[str, Any], data_module, seg_module, out_dir: str) -> HipTrainer:
+    """Same role as the reference's train(): build the trainer from config['hardware'] / ['hyperparams'], fit,
+    then run a final validation."""
+    check_batchnorm_and_batch_size(config, seg_module)
+    hw = config.get("hardware", {})
+    trainer = HipTrainer(accelerator=hw.get("accelerator", "gpu"), devices=hw.get("gpus_per_node", 1),
+                         strategy=hw.get("strategy", "auto"), num_nodes=hw.get("num_nodes", 1),
+                         max_epochs=config["hyperparams"]["num_epochs"], default_root_dir=out_dir,
+                         monitor=config.get("saving", {}).get("ckpt_monitor", "val_miou"),
+                         monitor_mode=config.get("saving", {}).get("ckpt_monitor_mode", "max"))
+    trainer.fit(seg_module, datamodule=data_module)
+    trainer.validate(seg_module, datamodule=data_module)
+    return trainer
+
+
+def predict(config: Dict[str, Any], data_module, seg_module, out_dir: str):
+    hw = config.get("hardware", {})
+    trainer = HipTrainer(accelerator=hw.get("accelerator", "gpu"), devices=hw.get("gpus_per_node", 1),
+                         strategy=hw.get("strategy", "auto"), num_nodes=hw.get("num_nodes", 1))
+    return trainer.predict(seg_module, datamodule=data_module, return_predictions=True)

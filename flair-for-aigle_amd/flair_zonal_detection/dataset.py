@@ -1,0 +1,88 @@
+"""Tile dataset of the zonal loop -- counterpart of the reference's flair_zonal_detection/dataset.py
+(MultiModalSlicedDataset :24, _load_patch :89-117, __getitem__ :174-209), mono-temporal modalities.
+
+Per tile and modality: a boundless windowed read of the tile box (zero fill outside the raster, bilinear
+resample to the modality's patch size) followed by the per-channel (x - mean) / std normalisation of
+flair_hub/data/utils_data/norm.py:37-44 ('custom'); 'without' leaves values as they are.
+
+Differences from the reference, all on the host side of the boundary:
+  * the raster objects are duck-typed (flair_zonal_detection.raster) instead of rasterio-only
+  * the '<MOD>_RAW' copy and the zero '<TASK>' label of the reference (dataset.py:194-207; 3 MB + 19.9 MB
+    of H2D traffic per tile that the model never reads) are only emitted with ``reference_batch_schema=True``;
+    FLAIR_HUB_Model falls back to the input size when no label rides along.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from flair_zonal_detection.raster import open_raster
+
+
+def normalize_array(img: np.ndarray, norm_type, means, stds) -> np.ndarray:
+    if norm_type not in ("scaling", "custom", "without", None):
+        raise ValueError("Normalization argument should be 'scaling', 'custom', or 'without'.")
+    if norm_type == "custom":
+        if len(means) != len(stds):
+            raise ValueError("If using 'custom', the provided means and stds must have the same length.")
+        img = img.astype(np.float64)
+        for i in range(img.shape[0]):
+            img[i] -= means[i]
+            img[i] /= stds[i]
+    elif norm_type == "scaling":
+        info = np.iinfo(img.dtype) if np.issubdtype(img.dtype, np.integer) else None
+        img = img.astype(np.float64) / info.max if info is not None else img.astype(np.float64)
+    return img
+
+
+class MultiModalSlicedDataset(Dataset):
+    def __init__(self, dataframe, modality_cfgs: Dict[str, Dict[str, Any]], patch_size_dict: Dict[str, int],
+                 ref_date_str: str, modalities_config: Dict[str, Any], reference_batch_schema: bool = False) -> None:
+        if any(m.endswith("_TS") for m in modality_cfgs):
+            raise NotImplementedError("time-series modalities are not implemented on libflairhip yet")
+        self.df = dataframe
+        self.modalities = modality_cfgs
+        self.modalities_config = modalities_config
+        self.patch_sizes = patch_size_dict
+        self.ref_date_str = ref_date_str
+        self.reference_batch_schema = reference_batch_schema
+        self.readers = {m: open_raster(cfg["input_img_path"]) for m, cfg in modality_cfgs.items()}
+
+    def __len__(self) -> int:
+        return len(self.df)
+
+    @staticmethod
+    def _tile_box(row):
+        g = row["geometry"]
+        return g.bounds if hasattr(g, "bounds") else tuple(g)  # (minx, miny, maxx, maxy)
+
+    def _load_patch(self, reader, bounds, cfg, patch_size: int) -> np.ndarray:
+        if hasattr(reader, "read_bounds"):
+            return reader.read_bounds(cfg["channels"], bounds, patch_size)
+        from rasterio.enums import Resampling  # type: ignore
+        from rasterio.windows import from_bounds  # type: ignore
+        window = from_bounds(*bounds, transform=reader.transform)
+        return reader.read(indexes=cfg["channels"], window=window, out_shape=(len(cfg["channels"]), patch_size,
+                           patch_size), resampling=Resampling.bilinear, boundless=True, fill_value=0)
+
+    def __getitem__(self, idx: int) -> Dict[str, torch.Tensor]:
+        row = self.df.iloc[idx]
+        bounds = self._tile_box(row)
+        out: Dict[str, torch.Tensor] = {}
+        for mod, cfg in self.modalities.items():
+            patch = self._load_patch(self.readers[mod], bounds, cfg, self.patch_sizes[mod])
+            ncfg = cfg.get("normalization", {})
+            norm = normalize_array(patch, ncfg.get("type"), ncfg.get("means"), ncfg.get("stds")) if ncfg else patch
+            out[mod] = torch.tensor(np.ascontiguousarray(norm), dtype=torch.float32)
+            if self.reference_batch_schema:
+                out[mod + "_RAW"] = torch.tensor(np.ascontiguousarray(patch), dtype=torch.float32)
+        out["index"] = torch.tensor([idx], dtype=torch.long)
+        if self.reference_batch_schema:
+            ref_size = list(self.patch_sizes.values())[0]
+            for task in self.modalities_config["labels"]:
+                k = len(self.modalities_config["labels_configs"][task]["value_name"])
+                out[task] = torch.zeros((k, ref_size, ref_size), dtype=torch.float32)
+        return out

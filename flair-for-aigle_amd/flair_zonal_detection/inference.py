@@ -1,0 +1,224 @@
+"""Zonal tiled inference -- counterpart of the reference's flair_zonal_detection/inference.py
+(prep_config :54-73, initialize_geometry_and_resolutions :76-132, prep_dataset :136-154, init_outputs
+:157-208, inference_and_write :254-355, run_inference :644-674).
+
+The tile loop keeps the reference's semantics -- per tile: drop the margin, convert to uint8, place the
+window at int(round((left - L) / res)), int(round((T - top) / res)), clip to the raster, skip empty windows,
+last writer wins -- and moves the per-pixel work onto the GPU:
+
+    reference (per tile)                             here (per batch)
+    D2H of f32 logits, 19.9 MB                       margin crop + argmax / class_prob fused in one HIP kernel
+    numpy argmax over 19 x 432 x 432                 over the whole batch (ffa_predict_u8), D2H of uint8:
+    scipy nearest zoom (optional)                    0.19 MB per tile; window maths by ffa_write_window
+    rasterio window write                            (bit-exact with inference.py:318-335), then the same write
+
+Polygonisation (:359-466, :566-630), geozone loading (:229-252) and COG conversion are product glue outside
+the hot path and are not provided.
+"""
+from __future__ import annotations
+
+import glob
+import logging
+import os
+import time
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from flairhip import ops
+from flair_zonal_detection.config import config_recap_1, config_recap_2, load_config, validate_config
+from flair_zonal_detection.dataset import MultiModalSlicedDataset
+from flair_zonal_detection.model_utils import build_inference_model, compute_patch_sizes
+from flair_zonal_detection.postprocess import convert  # noqa: F401  (re-exported like the reference)
+from flair_zonal_detection.raster import ArrayRaster, make_window, open_raster
+from flair_zonal_detection.slicing import generate_patches_from_reference
+
+logger = logging.getLogger(__name__)
+
+
+def overwrite_config(config: dict, model_ckpt_path: str, model_threshold_filepath: str, result_folder: str,
+                     log_folder: str) -> Dict:
+    config["model_weights"] = model_ckpt_path
+    config["model_threshold_filepath"] = model_threshold_filepath
+    config["output_path"] = result_folder
+    config["log_folder"] = log_folder
+    return config
+
+
+def prep_config(config_path: str, model_ckpt_path: Optional[str] = None, model_threshold_filepath: Optional[str] = None,
+                result_folder: Optional[str] = None, log_folder: Optional[str] = None,
+                images_folder: Optional[str] = None) -> Dict:
+    """Load + validate the YAML, resolve geometry, pick the device.  Accepts the fork's six-argument call
+    (scripts/run_fast_aigle_segmentation.py:75) and upstream FLAIR-HUB's one-argument call."""
+    config = load_config(config_path) if isinstance(config_path, str) else config_path
+    if images_folder is not None:
+        rasters = sorted(glob.glob(os.path.join(images_folder, "*.jp2")))
+        if not rasters:
+            raise FileNotFoundError(f"no *.jp2 raster in {images_folder}")
+        config["modalities"]["AERIAL_RGBI"]["input_img_path"] = rasters[0]
+    if model_ckpt_path is not None:
+        config = overwrite_config(config, model_ckpt_path, model_threshold_filepath, result_folder, log_folder)
+    validate_config(config)
+    config_recap_1(config)
+    config = initialize_geometry_and_resolutions(config)
+    config_recap_2(config)
+    use_gpu = config.get("use_gpu", True)
+    if not (use_gpu and torch.cuda.is_available()):
+        raise RuntimeError("the libflairhip tile loop needs an MI355X (use_gpu must be true and a GPU present); "
+                           "there is no CPU path in the product")
+    config["device"] = torch.device("cuda")
+    config["output_type"] = config.get("output_type", "argmax")
+    return config
+
+
+def initialize_geometry_and_resolutions(config: Dict) -> Dict:
+    """reference_resolution (finest active modality, rounded to 5 decimals), per-modality resolutions, image
+    bounds / shape, tile and margin size in metres; bounds of all active modalities must agree within 1e-2."""
+    modalities = config["modalities"]
+    active = [m for m, on in modalities["inputs"].items() if on]
+    resolutions, bounds = {}, []
+    for mod in active:
+        path = modalities[mod]["input_img_path"]
+        src = open_raster(path)
+        try:
+            resolutions[mod] = round(src.res[0], 5)
+            bounds.append((mod, src.bounds))
+            if "image_shape_px" not in config:
+                config["image_shape_px"] = {"height": src.height, "width": src.width}
+        finally:
+            if isinstance(path, (str, bytes)):
+                src.close()
+    ref_mod, ref_bounds = bounds[0]
+    for mod, b in bounds[1:]:
+        if not np.allclose(tuple(b), tuple(ref_bounds), atol=1e-2):
+            raise ValueError(f"Bounds mismatch between '{ref_mod}' and '{mod}':\n  {ref_mod}: {ref_bounds}\n  {mod}: {b}")
+    ref_mod, reference_resolution = min(resolutions.items(), key=lambda kv: kv[1])
+    config["reference_modality"] = ref_mod
+    config["reference_resolution"] = reference_resolution
+    config["modality_resolutions"] = resolutions
+    config["image_bounds"] = {"left": ref_bounds.left, "bottom": ref_bounds.bottom, "right": ref_bounds.right,
+                              "top": ref_bounds.top}
+    config["tile_size_m"] = round(config["img_pixels_detection"] * reference_resolution, 2)
+    config["margin_size_m"] = round(config["margin"] * reference_resolution, 2)
+    return config
+
+
+def prep_dataset(config: Dict, tiles_gdf, patch_sizes: Dict[str, int]) -> MultiModalSlicedDataset:
+    active = [m for m, on in config["modalities"]["inputs"].items() if on]
+    config["labels"] = [t["name"] for t in config["tasks"] if t["active"]]
+    config["labels_configs"] = {t["name"]: {"value_name": t["class_names"]} for t in config["tasks"] if t["active"]}
+    return MultiModalSlicedDataset(dataframe=tiles_gdf, modality_cfgs={m: config["modalities"][m] for m in active},
+                                   patch_size_dict=patch_sizes, ref_date_str=config.get("multitemp_model_ref_date", "05-15"),
+                                   modalities_config=config)
+
+
+def init_outputs(config: Dict, ref_img, i=None) -> Tuple[Dict[str, object], Dict[str, str]]:
+    """One uint8 output raster per active task (1 band for argmax, K for class_prob), on the reference raster's
+    grid or on an output_px_meters grid when that differs from the reference resolution."""
+    output_type = config["output_type"]
+    ref_res = config["reference_resolution"]
+    out_res = config.get("output_px_meters", ref_res)
+    ib = config["image_bounds"]
+    needs_rescale = abs(ref_res - out_res) > 1e-6
+    outputs, paths = {}, {}
+    for task in config["tasks"]:
+        if not task["active"]:
+            continue
+        k = len(task["class_names"])
+        count = k if output_type == "class_prob" else 1
+        suffix = "argmax" if output_type == "argmax" else "class-prob"
+        path = os.path.join(config["output_path"], f"{config['output_name']}_{task['name']}_{suffix}_i.tif")
+        if needs_rescale:
+            h = int(round((ib["top"] - ib["bottom"]) / out_res))
+            w = int(round((ib["right"] - ib["left"]) / out_res))
+        else:
+            h, w = ref_img.height, ref_img.width
+        if isinstance(ref_img, ArrayRaster):
+            outputs[task["name"]] = ArrayRaster(np.zeros((count, h, w), np.uint8), ib["left"], ib["top"], out_res,
+                                                ref_img.crs)
+        else:
+            import rasterio  # type: ignore
+            from rasterio.transform import from_origin  # type: ignore
+            profile = ref_img.profile.copy()
+            profile.update({"count": count, "dtype": "uint8", "compress": "lzw"})
+            if needs_rescale:
+                profile.update({"driver": "GTiff", "height": h, "width": w,
+                                "transform": from_origin(ib["left"], ib["top"], out_res, out_res)})
+            outputs[task["name"]] = rasterio.open(path, "w", **profile)
+        paths[task["name"]] = path
+    return outputs, paths
+
+
+def _nearest_zoom(pred: torch.Tensor, scale: float) -> torch.Tensor:
+    """scipy.ndimage.zoom(order=0) semantics on the last two axes (reference :212-226): output size
+    round(n * scale), source index = floor of the centre-aligned coordinate scipy uses for order 0."""
+    h, w = pred.shape[-2:]
+    oh, ow = int(round(h * scale)), int(round(w * scale))
+    ys = torch.clamp(torch.round(torch.arange(oh, device=pred.device) * ((h - 1) / max(oh - 1, 1))).long(), 0, h - 1)
+    xs = torch.clamp(torch.round(torch.arange(ow, device=pred.device) * ((w - 1) / max(ow - 1, 1))).long(), 0, w - 1)
+    return pred[..., ys, :][..., xs]
+
+
+@torch.no_grad()
+def inference_and_write(model: torch.nn.Module, dataloader: DataLoader, tiles_gdf, config: Dict,
+                        output_files: Dict[str, object], ref_img) -> None:
+    device = config["device"]
+    margin = config["margin"]
+    tile_size = config["img_pixels_detection"]
+    output_type = config["output_type"]
+    if output_type not in ("argmax", "class_prob"):
+        raise ValueError(f"Unknown output type: {output_type}")
+    ref_res = config["reference_resolution"]
+    out_res = config.get("output_px_meters", ref_res)
+    needs_rescale = abs(ref_res - out_res) > 1e-6
+    scale = ref_res / out_res if needs_rescale else 1.0
+    img_bounds = tuple(ref_img.bounds)  # (left, bottom, right, top)
+    keep = tile_size - 2 * margin
+
+    for batch in dataloader:
+        inputs = {k: v.to(device, non_blocking=True) for k, v in batch.items() if k != "index" and torch.is_tensor(v)}
+        indices = batch["index"].cpu().numpy().flatten()
+        rows = tiles_gdf.iloc[indices]
+        logits_tasks, _ = model(inputs)
+        for task_name, logits in logits_tasks.items():
+            nhwc = logits._ffa_nhwc
+            pred = ops.predict_u8(nhwc, logits._ffa_classes, output_type, crop=(margin, margin, keep, keep))
+            if needs_rescale:
+                pred = _nearest_zoom(pred, scale)
+            pred = pred.cpu().numpy()  # uint8: [B,h,w] or [B,K,h,w]
+            for i in range(len(indices)):
+                row = rows.iloc[i]
+                p = pred[i]
+                win = ops.write_window(row["left"], row["top"], img_bounds, out_res, p.shape[-2], p.shape[-1])
+                if win.skip:
+                    logger.info("skipping tile %s: window out of bounds", row["id"])
+                    continue
+                p = p[..., :win.height, :win.width]
+                window = make_window(win.col_off, win.row_off, win.width, win.height)
+                if output_type == "argmax":
+                    output_files[task_name].write(p, 1, window=window)
+                else:
+                    for c in range(p.shape[0]):
+                        output_files[task_name].write(p[c], c + 1, window=window)
+    for dst in output_files.values():
+        dst.close()
+
+
+def run_inference(config_path, ref_raster=None, geozone=None) -> Dict[str, object]:
+    """End-to-end zonal run with upstream FLAIR-HUB's one-argument semantics (the fork's own run_inference is
+    stale: inference.py:650-665 calls its helpers with the wrong arity).  Returns the output rasters."""
+    t0 = time.time()
+    config = prep_config(config_path)
+    ref_path = config["modalities"][config["reference_modality"]]["input_img_path"]
+    ref_img = ref_raster if ref_raster is not None else open_raster(ref_path)
+    tiles = generate_patches_from_reference(config, ref_img, geozone)
+    patch_sizes = compute_patch_sizes(config)
+    model = build_inference_model(config, patch_sizes).to(config["device"])
+    dataset = prep_dataset(config, tiles, patch_sizes)
+    loader = DataLoader(dataset, batch_size=config.get("batch_size", 8), num_workers=config.get("num_worker", 0))
+    outputs, _ = init_outputs(config, ref_img)
+    inference_and_write(model, loader, tiles, config, outputs, ref_img)
+    logger.info("zonal inference of %d tiles took %.1f s", len(tiles), time.time() - t0)
+    return outputs

@@ -1,0 +1,321 @@
+"""nn.Module / autograd layer over flairhip.ops.
+
+Modules keep torch-compatible parameters (conv weights OIHW f32, BatchNorm weight / bias /
+running stats) under the names segmentation_models_pytorch 0.4.0 emits, so reference checkpoints
+load unchanged (flair_hub/models/checkpoint.py:225-228 hard-codes some of those names).  The
+forward / backward arithmetic is entirely libflairhip kernels on NHWC tensors; torch supplies
+autograd bookkeeping, parameters and the optimizer.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+LOGIT_PITCH = 32  # channel pitch of logits tensors (>= any class count of the reference's tasks)
+
+
+def _as_nhwc_grad(g: torch.Tensor) -> torch.Tensor:
+    return g if g.is_contiguous() else g.contiguous()
+
+
+class HipConv2d(nn.Module):
+    """Parameter holder mirroring nn.Conv2d (weight OIHW f32, optional bias)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int, stride: int = 1, padding: int = 0,
+                 bias: bool = False):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        self._cache = {}
+
+    @property
+    def in_pitch(self) -> int:
+        return ops.pad_channels(self.in_channels)
+
+    @property
+    def out_pitch(self) -> int:
+        return LOGIT_PITCH if self.bias is not None and self.out_channels <= LOGIT_PITCH else ops.pad_channels(
+            self.out_channels)
+
+    def packed(self, dtype: torch.dtype, transpose: bool = False, scale: Optional[torch.Tensor] = None,
+               tag: str = "") -> ops.PackedWeight:
+        """MFMA operand for the current weight values; re-packed only when the parameter changed."""
+        key = (dtype, transpose, tag)
+        ver = (self.weight._version, self.weight.data_ptr(), None if scale is None else scale._version)
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        w = self.weight.detach()
+        if not w.is_contiguous():
+            w = w.contiguous()
+        pitch = self.out_pitch if transpose else self.in_pitch
+        pw = ops.pack_conv_weight(w, dtype, self.stride, pitch, transpose=transpose, scale=scale)
+        self._cache[key] = (ver, pw)
+        return pw
+
+    def extra_repr(self) -> str:
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
+                f"padding={self.padding}, bias={self.bias is not None}")
+
+
+class HipBatchNorm2d(nn.Module):
+    """Parameter / buffer holder mirroring nn.BatchNorm2d (eps 1e-5, momentum 0.1)."""
+
+    def __init__(self, num_features: int, eps: float = 1e-5, momentum: float = 0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._pending_batches = 0
+        self._register_state_dict_hook(HipBatchNorm2d._flush_hook)
+
+    def note_batch(self) -> None:
+        self._pending_batches += 1  # folded into the device counter lazily (no per-step launch)
+
+    @staticmethod
+    def _flush_hook(module, state_dict, prefix, local_metadata):
+        if module._pending_batches:
+            module.num_batches_tracked += module._pending_batches
+            module._pending_batches = 0
+            state_dict[prefix + "num_batches_tracked"] = module.num_batches_tracked
+
+    def extra_repr(self) -> str:
+        return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}"
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd functions (all tensors NHWC)
+
+class _ConvBnAct(torch.autograd.Function):
+    """y = relu?( batch_norm_train(conv(x)) (+ residual) )"""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, conv: HipConv2d, bn: HipBatchNorm2d, relu: bool):
+        pw = conv.packed(x.dtype)
+        y0 = ops.conv2d(x, pw, conv.padding, conv.out_pitch)
+        scale, shift, mean, rstd = ops.bn_stats(y0, gamma, beta, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+        bn.note_batch()
+        y = ops.bn_apply(y0, scale, shift, residual=residual, relu=relu)
+        ctx.conv, ctx.relu, ctx.has_res = conv, relu, residual is not None
+        ctx.save_for_backward(x, y0, y if relu else None, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y0, y, gamma, mean, rstd = ctx.saved_tensors
+        conv = ctx.conv
+        dy = _as_nhwc_grad(dy)
+        want_res = ctx.has_res and ctx.needs_input_grad[4]
+        d0, dres, dgamma, dbeta = ops.bn_bwd(y0, dy, y, gamma, mean, rstd, ctx.relu, want_res)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            pwt = conv.packed(x.dtype, transpose=True)
+            k = conv.kernel_size
+            dx = ops.conv2d(d0, pwt, k - 1 - conv.padding, x.shape[-1], dil=conv.stride,
+                            out_hw=(x.shape[1], x.shape[2]))
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv_wgrad(x, d0, conv.out_channels, conv.in_channels, conv.kernel_size, conv.kernel_size,
+                                conv.stride, conv.padding)
+        return dx, dw, dgamma, dbeta, dres, None, None, None
+
+
+class _ConvBias(torch.autograd.Function):
+    """y = conv(x) + bias  (segmentation head; output pitch LOGIT_PITCH, pad channels zero)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, conv: HipConv2d):
+        pw = conv.packed(x.dtype)
+        bpad = None
+        if bias is not None:
+            bpad = torch.zeros(conv.out_pitch, dtype=torch.float32, device=x.device)
+            bpad[: conv.out_channels] = bias.detach()
+        y = ops.conv2d(x, pw, conv.padding, conv.out_pitch, bias=bpad)
+        ctx.conv, ctx.has_bias = conv, bias is not None
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        conv = ctx.conv
+        dy = _as_nhwc_grad(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            pwt = conv.packed(x.dtype, transpose=True)
+            k = conv.kernel_size
+            dx = ops.conv2d(dy, pwt, k - 1 - conv.padding, x.shape[-1], dil=conv.stride,
+                            out_hw=(x.shape[1], x.shape[2]))
+        dw = ops.conv_wgrad(x, dy, conv.out_channels, conv.in_channels, conv.kernel_size, conv.kernel_size,
+                            conv.stride, conv.padding) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            s, _ = ops.channel_sums(dy)
+            db = s[: conv.out_channels].clone()
+        return dx, dw, db, None
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y, idx = ops.maxpool3x3s2_fwd(x)
+        ctx.save_for_backward(idx)
+        ctx.in_hw = (x.shape[1], x.shape[2])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return ops.maxpool3x3s2_bwd(_as_nhwc_grad(dy), idx, ctx.in_hw)
+
+
+class _UpConcat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lo, skip):
+        ctx.c1 = lo.shape[-1]
+        return ops.upsample2x_concat_fwd(lo, skip)
+
+    @staticmethod
+    def backward(ctx, dcat):
+        dlo, dskip = ops.upsample2x_concat_bwd(_as_nhwc_grad(dcat), ctx.c1)
+        return dlo, dskip
+
+
+class _Bilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, out_hw):
+        ctx.in_hw = (x.shape[1], x.shape[2])
+        return ops.bilinear_fwd(x, out_hw)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.bilinear_bwd(_as_nhwc_grad(dy), ctx.in_hw), None
+
+
+class _ToNHWC(torch.autograd.Function):
+    """f32 NCHW batch tensor -> NHWC compute tensor (no gradient needed for network inputs, but the
+    generic-logits path of the loss uses the backward)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype, cp):
+        ctx.c = x.shape[1]
+        return ops.nchw_to_nhwc(x, dtype, cp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.nhwc_to_nchw(_as_nhwc_grad(dy), ctx.c), None, None
+
+
+class _SoftmaxCE(torch.autograd.Function):
+    """Weighted-mean CE over NHWC logits; backward recomputes the softmax and scales by grad_output
+    read on the device (no host sync)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, weights, num_classes, holder):
+        loss, wsum, _, pred = ops.softmax_ce(logits, targets, weights, num_classes, want_grad=False, want_pred=True)
+        if holder is not None:
+            holder["pred"] = pred
+            holder["wsum"] = wsum
+        ctx.save_for_backward(logits, targets, weights)
+        ctx.k = num_classes
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, targets, weights = ctx.saved_tensors
+        gs = g.detach().reshape(1).float().contiguous()
+        _, _, dlogits, _ = ops.softmax_ce(logits, targets, weights, ctx.k, grad_scale=gs, want_grad=True)
+        return dlogits, None, None, None, None
+
+
+def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, relu: bool = True, residual=None):
+    """Training: conv -> batch-stat BN -> (+residual) -> ReLU.  Eval: BN folded into the conv
+    (scale into the packed weights, shift as bias) with the residual add / ReLU in the conv epilogue."""
+    if bn.training:
+        return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, conv, bn, relu)
+    ver = (conv.weight._version, conv.weight.data_ptr(), bn.weight._version, bn.bias._version,
+           bn.running_mean._version, bn.running_var._version, x.dtype)
+    hit = conv._cache.get("eval_fold")
+    if hit is None or hit[0] != ver:
+        scale, shift = ops.bn_eval_params(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                          bn.eps)
+        w = conv.weight.detach()
+        pw = ops.pack_conv_weight(w if w.is_contiguous() else w.contiguous(), x.dtype, conv.stride, conv.in_pitch,
+                                  scale=scale)
+        hit = (ver, pw, shift)
+        conv._cache["eval_fold"] = hit
+    return ops.conv2d(x, hit[1], conv.padding, conv.out_pitch, bias=hit[2], residual=residual, relu=relu)
+
+
+def conv_bias(x, conv: HipConv2d):
+    return _ConvBias.apply(x, conv.weight, conv.bias, conv)
+
+
+def max_pool(x):
+    return _MaxPool.apply(x)
+
+
+def up_concat(lo, skip):
+    return _UpConcat.apply(lo, skip)
+
+
+def bilinear(x, out_hw):
+    if (x.shape[1], x.shape[2]) == tuple(out_hw):
+        return x  # align_corners=False resize to the same size is the identity (flair_model.py:327 on U-Net@512)
+    return _Bilinear.apply(x, tuple(out_hw))
+
+
+def to_nhwc(x_nchw: torch.Tensor, dtype: torch.dtype, cp: Optional[int] = None) -> torch.Tensor:
+    return _ToNHWC.apply(x_nchw, dtype, cp)
+
+
+def logits_view(y_nhwc: torch.Tensor, num_classes: int) -> torch.Tensor:
+    """[B,K,H,W]-shaped view of NHWC logits, as callers of the reference expect (NCHW semantics);
+    the underlying NHWC tensor rides along so the fused loss / argmax kernels can take the fast path."""
+    v = y_nhwc[..., :num_classes].permute(0, 3, 1, 2)
+    v._ffa_nhwc = y_nhwc
+    v._ffa_classes = num_classes
+    return v
+
+
+class HipCrossEntropyLoss(nn.Module):
+    """Drop-in for nn.CrossEntropyLoss(weight=w) as built by FLAIRLosses
+    (flair_hub/tasks/module_setup.py:150-161); also yields argmax(softmax(logits)) from the same pass."""
+
+    def __init__(self, weight: Optional[torch.Tensor] = None, num_classes: Optional[int] = None):
+        super().__init__()
+        if weight is None:
+            if num_classes is None:
+                raise ValueError("HipCrossEntropyLoss needs class weights or a class count")
+            weight = torch.ones(num_classes)
+        self.register_buffer("weight", weight.float().clone())
+        self.last = {}
+
+    @staticmethod
+    def prepare_targets(t: torch.Tensor) -> torch.Tensor:
+        if t.ndim == 4:  # one-hot NCHW (flair_hub/tasks/tasks_module.py:153)
+            return ops.onehot_to_index(t)
+        return t if (t.dtype == torch.uint8 and t.is_contiguous()) else t.to(torch.uint8).contiguous()
+
+    def forward(self, logits: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        k = self.weight.numel()
+        nhwc = getattr(logits, "_ffa_nhwc", None)
+        if nhwc is None:
+            if logits.ndim != 4 or logits.shape[1] != k:
+                raise ValueError(f"expected logits [B,{k},H,W], got {tuple(logits.shape)}")
+            nhwc = to_nhwc(logits.float().contiguous(), torch.float32, LOGIT_PITCH)
+        self.last = {}
+        return _SoftmaxCE.apply(nhwc, self.prepare_targets(targets), self.weight, k, self.last)
+
+    def last_prediction(self) -> Optional[torch.Tensor]:
+        return self.last.get("pred")

@@ -73,6 +73,7 @@ class PackedWeight:
     kh: int
     kw: int
     stride: int         # stride of the conv the operand is used for (1 for every dgrad operand)
+    ch_real: int = 0    # real (unpadded) reduction channels
 
 
 def pack_conv_weight(w_oihw: torch.Tensor, dtype: torch.dtype, stride: int, ci_pitch: int,
@@ -94,7 +95,7 @@ def pack_conv_weight(w_oihw: torch.Tensor, dtype: torch.dtype, stride: int, ci_p
     dst = torch.empty(nbytes // (2 if dtype == torch.bfloat16 else 4), dtype=dtype, device=w_oihw.device)
     _l.check(lib.ffa_pack_conv_weight(did, w_oihw.data_ptr(), _ptr(scale), dst.data_ptr(), O, I, kh, kw,
                                       1 if transpose else 0, rows, ci_pitch, bco, rg, _stream()), "pack_conv_weight")
-    return PackedWeight(dst, rows, rows_real, ci_pitch, bco, kh, kw, use_stride)
+    return PackedWeight(dst, rows, rows_real, ci_pitch, bco, kh, kw, use_stride, O if transpose else I)
 
 
 def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:
@@ -200,6 +201,18 @@ def bn_bwd(x: torch.Tensor, dy: torch.Tensor, y: Optional[torch.Tensor], gamma, 
                             rstd.data_ptr(), dx.data_ptr(), _ptr(dres), dgb[0].data_ptr(), dgb[1].data_ptr(),
                             x.numel() // C_, C_, 1 if relu else 0, ws.data_ptr(), ws.numel(), _stream()), "bn_bwd")
     return dx, dres, dgb[0], dgb[1]
+
+
+def channel_sums(x: torch.Tensor):
+    """Per-channel (sum, sum of squares) over all pixels of an NHWC tensor, f32."""
+    lib = _l.load()
+    _chk_nhwc(x, "channel_sums input")
+    C_ = x.shape[-1]
+    out = torch.empty((2, C_), dtype=torch.float32, device=x.device)
+    ws = workspace(lib.ffa_bn_workspace_bytes(C_), x.device, "bn")
+    _l.check(lib.ffa_channel_sums(_dt(x), x.data_ptr(), x.numel() // C_, C_, out[0].data_ptr(), out[1].data_ptr(),
+                                  ws.data_ptr(), ws.numel(), _stream()), "channel_sums")
+    return out[0], out[1]
 
 
 def maxpool3x3s2_fwd(x: torch.Tensor):

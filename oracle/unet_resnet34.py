@@ -1,0 +1,134 @@
+"""ORACLE -- test infrastructure only (imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by the product path under flair-for-aigle_amd/).
+
+Plain torch fp32 / NCHW / eager restatement of the conv stack the reference obtains from the absent
+third-party dependency segmentation-models-pytorch==0.4.0 (reference requirements.txt:12) through
+flair_hub/models/monotemp_model.py:68-92:  smp.Unet(encoder_name='resnet34') split into
+``.encoder`` and ``.decoder`` + ``.segmentation_head`` (monotemp_model.py:94-97).
+
+PARITY STATUS: the reference repository holds no tests, golden vectors or fixtures for this path and
+smp/timm are not installed here, so the ARCHITECTURE is restated from the published smp 0.4.0 /
+torchvision sources and pinned only by
+  * the parameter count smp publishes for Unet-ResNet34 (24,436,369 @ in=3, classes=1) and
+  * the state-dict key names the reference itself hard-codes (flair_hub/models/checkpoint.py:225-228).
+The ARITHMETIC is torch.nn.functional on CPU -- the very ATen ops smp would call -- so op-level
+parity with this file is parity with the reference's accelerator=cpu path ("parity unpinned" by
+reference-side vectors).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ENCODER_WIDTHS = (64, 128, 256, 512)
+ENCODER_BLOCKS = (3, 4, 6, 3)
+DECODER_CHANNELS = (256, 128, 64, 32, 16)
+
+
+class BasicBlock(nn.Module):
+    # torchvision.models.resnet.BasicBlock, which smp's ResNetEncoder inherits
+    def __init__(self, cin: int, cout: int, stride: int):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = F.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return F.relu(out + identity)
+
+
+class ResNet34Encoder(nn.Module):
+    """smp.encoders.resnet.ResNetEncoder(depth=5): returns [x, stem, layer1, layer2, layer3, layer4]."""
+
+    def __init__(self, in_channels: int = 3):
+        super().__init__()
+        self.out_channels = (in_channels, 64, 64, 128, 256, 512)
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        cin = 64
+        for li, (w, n) in enumerate(zip(ENCODER_WIDTHS, ENCODER_BLOCKS), start=1):
+            blocks = []
+            for b in range(n):
+                blocks.append(BasicBlock(cin, w, 2 if (b == 0 and li > 1) else 1))
+                cin = w
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+        for m in self.modules():  # torchvision's un-pretrained init
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        feats = [x]
+        x = F.relu(self.bn1(self.conv1(x)))
+        feats.append(x)
+        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        for li in range(1, 5):
+            x = getattr(self, f"layer{li}")(x)
+            feats.append(x)
+        return feats
+
+
+class DecoderBlock(nn.Module):
+    # smp.decoders.unet.decoder.DecoderBlock with use_batchnorm=True, attention_type=None
+    def __init__(self, cin: int, cskip: int, cout: int):
+        super().__init__()
+        self.conv1 = nn.Sequential(nn.Conv2d(cin + cskip, cout, 3, padding=1, bias=False), nn.BatchNorm2d(cout),
+                                   nn.ReLU(inplace=True))
+        self.conv2 = nn.Sequential(nn.Conv2d(cout, cout, 3, padding=1, bias=False), nn.BatchNorm2d(cout),
+                                   nn.ReLU(inplace=True))
+
+    def forward(self, x, skip=None):
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        if skip is not None:
+            x = torch.cat([x, skip], dim=1)
+        return self.conv2(self.conv1(x))
+
+
+class UnetDecoder(nn.Module):
+    def __init__(self, encoder_channels, decoder_channels=DECODER_CHANNELS):
+        super().__init__()
+        enc = list(encoder_channels[1:])[::-1]  # drop the input-resolution identity, deepest first
+        in_ch = [enc[0]] + list(decoder_channels[:-1])
+        skip_ch = enc[1:] + [0]
+        self.blocks = nn.ModuleList(DecoderBlock(i, s, o) for i, s, o in zip(in_ch, skip_ch, decoder_channels))
+        for m in self.modules():  # smp.base.initialization.initialize_decoder
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="relu")
+
+    def forward(self, *features):
+        feats = list(features[1:])[::-1]
+        x, skips = feats[0], feats[1:]
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, skips[i] if i < len(skips) else None)
+        return x
+
+
+class SegmentationHead(nn.Sequential):
+    def __init__(self, cin: int, classes: int):
+        super().__init__(nn.Conv2d(cin, classes, 3, padding=1), nn.Identity(), nn.Identity())
+        nn.init.xavier_uniform_(self[0].weight)  # smp initialize_head
+        nn.init.constant_(self[0].bias, 0)
+
+
+class UnetResNet34(nn.Module):
+    """What smp.create_model(arch='unet', encoder_name='resnet34', classes, in_channels) returns."""
+
+    def __init__(self, in_channels: int = 3, classes: int = 1):
+        super().__init__()
+        self.encoder = ResNet34Encoder(in_channels)
+        self.decoder = UnetDecoder(self.encoder.out_channels)
+        self.segmentation_head = SegmentationHead(DECODER_CHANNELS[-1], classes)
+
+    def forward(self, x):
+        return self.segmentation_head(self.decoder(*self.encoder(x)))
+
+
+def count_parameters(m: nn.Module) -> int:
+    return sum(p.numel() for p in m.parameters())

@@ -1,0 +1,349 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE'S OWN CODE
+(/root/reference, read-only) in the build container.
+
+The reference has no tests and its third-party dependencies (rasterio, geopandas, shapely, pytorch_lightning,
+torchmetrics, segmentation_models_pytorch, skimage) are not installed, so the modules are imported with
+small stand-in modules injected into sys.modules for those imports ONLY inside this script:
+  * rasterio.open -> a fake dataset with .profile/.shape/.transform/.bounds; rasterio.mask.mask -> the crop
+    window of the scenario; rasterio.transform.array_bounds -> the affine formula rasterio uses
+  * geopandas.GeoDataFrame -> records list; shapely.geometry.box -> bounds tuple
+  * pytorch_lightning.LightningModule -> nn.Module with .log/.device; torchmetrics -> no-op metrics
+  * segmentation_models_pytorch.create_model -> oracle/unet_resnet34.UnetResNet34 (the conv stack itself
+    is third-party code absent from the reference tree; only the reference's GLUE around it is pinned here)
+Only data (inputs + the reference's outputs) is written; no reference source is copied.  The fixtures are
+committed; this script is not run on the GPU box (the reference does not travel).
+
+Usage:  python tests/golden/gen_goldens.py
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+# ---- stand-ins for the absent third-party modules ------------------------------------------------
+
+class FakeTransform(tuple):
+    """(a, b, c, d, e, f) affine, x = a*col + b*row + c, y = d*col + e*row + f"""
+
+
+def array_bounds(height, width, transform):
+    a, b, c, d, e, f = transform
+    w, n = c, f
+    e_, s = (width * a + height * b) + c, (width * d + height * e) + f
+    return w, s, e_, n
+
+
+class FakeBounds(tuple):
+    left = property(lambda s: s[0])
+    bottom = property(lambda s: s[1])
+    right = property(lambda s: s[2])
+    top = property(lambda s: s[3])
+
+
+class FakeRaster:
+    def __init__(self, left, top, res, height, width, crop=None):
+        self.transform = FakeTransform((res, 0.0, left, 0.0, -res, top))
+        self.shape = (height, width)
+        self.height, self.width = height, width
+        self.res = (res, res)
+        self.profile = {"crs": "EPSG:2154"}
+        self.crs = "EPSG:2154"
+        self.crop = crop  # (c0, r0, c1, r1) pixel window of raster INTERSECT geozone
+        self.bounds = FakeBounds(array_bounds(height, width, self.transform))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def close(self):
+        pass
+
+
+_current_raster = {}
+
+
+def fake_open(path, *a, **k):
+    return _current_raster[path]
+
+
+def fake_mask(src, geometries, crop=True):
+    if src.crop is None:
+        raise ValueError("Input shapes do not overlap raster.")
+    c0, r0, c1, r1 = src.crop
+    a, b, c, d, e, f = src.transform
+    out_transform = FakeTransform((a, b, (a * c0 + b * r0) + c, d, e, (d * c0 + e * r0) + f))
+    return np.zeros((1, r1 - r0, c1 - c0), dtype=np.uint8), out_transform
+
+
+class FakeGDF:
+    def __init__(self, rows=None, crs=None, geometry=None):
+        self.rows = list(rows or [])
+
+    def __len__(self):
+        return len(self.rows)
+
+
+class _Rows:
+    def __init__(self, rows):
+        self.rows = rows
+
+    @property
+    def iloc(self):
+        return self
+
+    def __getitem__(self, i):
+        if isinstance(i, (int, np.integer)):
+            return self.rows[int(i)]
+        return _Rows([self.rows[int(j)] for j in i])
+
+
+def install_stubs():
+    rio = _mod("rasterio", open=fake_open)
+    rio.mask = _mod("rasterio.mask", mask=fake_mask)
+    rio.transform = _mod("rasterio.transform", array_bounds=array_bounds, rowcol=None, from_origin=None)
+    rio.io = _mod("rasterio.io", DatasetReader=object)
+    rio.windows = _mod("rasterio.windows", Window=lambda col_off, row_off, width, height: (col_off, row_off, width, height),
+                       from_bounds=None)
+    rio.features = _mod("rasterio.features", shapes=None)
+    rio.enums = _mod("rasterio.enums", Resampling=types.SimpleNamespace(bilinear=1, nearest=0))
+    rio.shutil = _mod("rasterio.shutil", copy=None)
+    _mod("geopandas", GeoDataFrame=FakeGDF)
+    sh = _mod("shapely")
+    sh.geometry = _mod("shapely.geometry", box=lambda *a: tuple(a), Polygon=object, shape=None, mapping=None)
+    _mod("skimage", img_as_float=None)
+    _mod("tqdm", tqdm=lambda it, **k: it)
+
+    class LightningModule(torch.nn.Module):
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+        def log(self, *a, **k):
+            pass
+
+    pl = _mod("pytorch_lightning", LightningModule=LightningModule, LightningDataModule=object)
+    pl.utilities = _mod("pytorch_lightning.utilities")
+    pl.utilities.rank_zero = _mod("pytorch_lightning.utilities.rank_zero", rank_zero_only=lambda f: f)
+
+    class _NoMetric(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def update(self, *a, **k):
+            pass
+
+        def compute(self):
+            return torch.tensor(0.0)
+
+        def reset(self):
+            pass
+
+    tm = _mod("torchmetrics")
+    tm.classification = _mod("torchmetrics.classification", MulticlassJaccardIndex=_NoMetric)
+    tm.aggregation = _mod("torchmetrics.aggregation", MeanMetric=_NoMetric)
+
+    from oracle.unet_resnet34 import UnetResNet34
+
+    def create_model(arch, encoder_name, classes, in_channels, img_size=None, **kw):
+        if img_size is not None:
+            raise TypeError("img_size")  # what smp 0.4.0's Unet constructor does (SURVEY.md Appendix C caveat)
+        assert arch == "unet" and encoder_name.replace("tu-", "") == "resnet34", (arch, encoder_name)
+        return UnetResNet34(in_channels, classes)
+
+    _mod("segmentation_models_pytorch", create_model=create_model)
+    sys.path.insert(0, REF)
+
+
+def hexf(v):
+    return float(v).hex()
+
+
+# ---- scenarios ----------------------------------------------------------------------------------
+
+SLICING_SCENARIOS = [
+    # name, left, top, res, H, W, crop (c0,r0,c1,r1) or None = whole raster, patch, margin
+    ("bdortho_5km_full", 651000.0, 6865000.0, 0.2, 25000, 25000, None, 512, 40),
+    ("odd_origin_crop", 651992.36, 6860417.84, 0.2, 6173, 7311, (117, 301, 5120, 6002), 512, 40),
+    ("small_single_tile", 1000.5, 2000.25, 0.2, 400, 380, None, 512, 40),
+    ("exact_multiple", 0.0, 86.4 * 4, 0.2, 432 * 4, 432 * 3, None, 512, 40),
+    ("coarse_res_margin0", 300000.0, 6500000.0, 0.5, 3000, 2111, (10, 0, 2100, 2950), 256, 0),
+    ("res_rounding_1p5", 12345.678, 98765.432, 1.5, 1777, 901, None, 128, 16),
+    ("no_overlap", 0.0, 100.0, 0.2, 500, 500, "none", 512, 40),
+]
+
+
+def gen_slicing(out):
+    import flair_zonal_detection.slicing as ref_slicing
+    for name, left, top, res, H, W, crop, patch, margin in SLICING_SCENARIOS:
+        ras = FakeRaster(left, top, res, H, W, None if crop == "none" else (crop or (0, 0, W, H)))
+        _current_raster["img"] = ras
+        cfg = {"img_pixels_detection": patch, "margin": margin, "output_path": "/tmp", "output_name": "golden",
+               "reference_modality": "AERIAL_RGBI", "reference_resolution": round(res, 5)}
+        gdf = ref_slicing.generate_patches_from_reference(cfg, "img", geozone_contour_geometries=[object()])
+        small = len(gdf.rows) <= 200
+        tiles = []
+        for r in gdf.rows:
+            t = {"id": r["id"], "left": hexf(r["left"]), "bottom": hexf(r["bottom"]), "right": hexf(r["right"]),
+                 "top": hexf(r["top"])}
+            if small:  # shapely.geometry.box(x_min, y_max, x_max, y_min) argument order -> (x0, y0, x1, y1)
+                t["box"] = [hexf(v) for v in (r["geometry"][0], r["geometry"][3], r["geometry"][2], r["geometry"][1])]
+            tiles.append(t)
+        zone = [hexf(gdf.rows[0][k]) for k in ("left_o", "bottom_o", "right_o", "top_o")] if gdf.rows else None
+        out[name] = {"raster": {"left": left, "top": top, "res": res, "height": H, "width": W}, "zone": zone,
+                     "crop": None if crop in (None, "none") else list(crop), "no_overlap": crop == "none",
+                     "patch": patch, "margin": margin, "reference_resolution": round(res, 5),
+                     "n_tiles": len(tiles), "tiles": tiles}
+        print(f"  slicing {name}: {len(tiles)} tiles")
+
+
+def gen_windows(slicing, out):
+    """inference_and_write of the reference with a fake model / loader / output raster: records the windows."""
+    import flair_zonal_detection.inference as ref_inf
+
+    class Recorder:
+        def __init__(self):
+            self.calls = []
+
+        def write(self, arr, band, window=None):
+            self.calls.append((list(window), list(arr.shape), int(band)))
+
+        def close(self):
+            pass
+
+    for name in ("odd_origin_crop", "small_single_tile", "res_rounding_1p5", "coarse_res_margin0"):
+        sc = slicing[name]
+        r = sc["raster"]
+        ras = FakeRaster(r["left"], r["top"], r["res"], r["height"], r["width"])
+        rows = [{"id": t["id"], "left": float.fromhex(t["left"]), "top": float.fromhex(t["top"])} for t in sc["tiles"]]
+        tiles_gdf = _Rows(rows)
+        patch, margin = sc["patch"], sc["margin"]
+        for out_res in (sc["reference_resolution"], sc["reference_resolution"] * 2):
+            idx = list(range(len(rows)))[:64]
+
+            class Model(torch.nn.Module):
+                def forward(self, inputs):
+                    b = inputs["AERIAL_RGBI"].shape[0]
+                    return {"T": torch.zeros(b, 3, patch, patch)}, {}
+
+            loader = [{"AERIAL_RGBI": torch.zeros(len(idx), 1, 4, 4), "index": torch.tensor(idx)[:, None]}]
+            rec = Recorder()
+            cfg = {"device": "cpu", "margin": margin, "img_pixels_detection": patch, "output_type": "argmax",
+                   "reference_resolution": sc["reference_resolution"], "output_px_meters": out_res}
+            ref_inf.inference_and_write(Model(), loader, tiles_gdf, cfg, {"T": rec}, ras)
+            out.append({"scenario": name, "out_res": hexf(out_res), "tile_indices": idx,
+                        "windows": [c[0] for c in rec.calls], "shapes": [c[1] for c in rec.calls]})
+            print(f"  windows {name} out_res={out_res}: {len(rec.calls)} writes")
+
+
+def gen_convert(path):
+    import flair_zonal_detection.postprocess as ref_pp
+    g = np.random.default_rng(7)
+    z = (g.standard_normal((19, 24, 20)) * 3).astype(np.float32)
+    z[:, 0, 0] = 0.5  # ties -> first index
+    z[3, 1, 1] = z[7, 1, 1] = 9.0
+    np.savez_compressed(path, logits=z, argmax=ref_pp.convert(z, "argmax"), class_prob=ref_pp.convert(z, "class_prob"))
+    try:
+        ref_pp.convert(z, "logits")
+        raised = False
+    except ValueError:
+        raised = True
+    assert raised
+    print("  convert: argmax / class_prob written")
+
+
+def gen_glue(path_json, path_npz):
+    """FLAIR_HUB_Model.forward + SegmentationTask.step + FLAIRLosses of the reference, on CPU, with the oracle
+    conv stack standing in for smp; plus compute_patch_sizes / prepare_model_config outputs."""
+    from flair_hub.tasks.module_setup import FLAIRLosses, build_segmentation_module
+    import flair_zonal_detection.model_utils as ref_mu
+    from flair_zonal_detection.inference import initialize_geometry_and_resolutions
+    sys.path.insert(0, os.path.join(ROOT, "flair-for-aigle_amd"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_cfgs", os.path.join(ROOT, "flair-for-aigle_amd", "flairhip", "configs.py"))
+    cfgs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cfgs)
+
+    cfg = cfgs.unet_resnet34_config(in_channels=5, precision="fp32")
+    cfg["models"]["monotemp_model"]["arch"] = "resnet34-unet"
+    w = FLAIRLosses(cfg).get_default_weights("AERIAL_LABEL-COSIA")
+    from oracle.seeded_weights import checksum, fill_state_dict
+    torch.manual_seed(2025)
+    task = build_segmentation_module(cfg, {"AERIAL_RGBI": 64}, stage="train")
+    task.model.load_state_dict(fill_state_dict(task.model.state_dict()))
+    wsum = checksum(task.model.state_dict())
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 5, 64, 64, generator=g)
+    t = torch.randint(0, 19, (2, 64, 64), generator=g)
+    onehot = torch.nn.functional.one_hot(t, 19).permute(0, 3, 1, 2).float()
+    task.eval()  # eval outputs first: the training step below moves the BatchNorm running statistics
+    with torch.no_grad():
+        logits_eval = task.model({"AERIAL_RGBI": x, "AERIAL_LABEL-COSIA": onehot})[0]["AERIAL_LABEL-COSIA"]
+        pred_step = task.predict_step({"AERIAL_RGBI": x, "AERIAL_LABEL-COSIA": onehot}, 0)
+    task.train()
+    loss, preds, targets = task.step({"AERIAL_RGBI": x, "AERIAL_LABEL-COSIA": onehot}, training=True)
+    loss.backward()
+    gn = torch.sqrt(sum((p.grad ** 2).sum() for p in task.model.parameters() if p.grad is not None))
+    np.savez_compressed(path_npz, x=x.numpy(), t=t.numpy().astype(np.uint8),
+                        logits_eval=logits_eval.numpy(), preds_train=preds["AERIAL_LABEL-COSIA"].numpy().astype(np.uint8),
+                        preds_eval=pred_step["preds_AERIAL_LABEL-COSIA"].numpy().astype(np.uint8))
+
+    # zonal config expansion
+    zonal = __import__("yaml").safe_load(open(os.path.join(REF, "configs/config_model_zonal_segmentation.yaml")))
+    zonal["monotemp_arch"] = "resnet34-unet"
+    zonal["model_weights"] = "/nonexistent/weights.safetensors"
+    __import__("yaml").safe_dump(zonal, open(os.path.join(HERE, "zonal_config.yaml"), "w"), sort_keys=False)  # the input of this run
+    _current_raster["/path/to/input_image.tif"] = FakeRaster(651992.36, 6860417.84, 0.2, 6173, 7311)
+    zonal = initialize_geometry_and_resolutions(zonal)
+    sizes = ref_mu.compute_patch_sizes(zonal)
+    mcfg = ref_mu.prepare_model_config(zonal)
+    info = {
+        "loss_weights": [float(v) for v in w],
+        "train_loss": hexf(loss.item()), "grad_norm": float(gn), "weights_checksum": wsum,
+        "state_dict_keys": sorted(task.state_dict().keys()),
+        "zonal": {"reference_resolution": zonal["reference_resolution"], "reference_modality": zonal["reference_modality"],
+                  "tile_size_m": zonal["tile_size_m"], "margin_size_m": zonal["margin_size_m"],
+                  "image_bounds": zonal["image_bounds"], "patch_sizes": sizes,
+                  "labels": mcfg["labels"], "n_classes": len(mcfg["labels_configs"]["AERIAL_LABEL-COSIA"]["value_name"]),
+                  "inputs_channels": mcfg["modalities"]["inputs_channels"], "aux_loss": mcfg["modalities"]["aux_loss"],
+                  "pre_processings": mcfg["modalities"]["pre_processings"],
+                  "monotemp_model": mcfg["models"]["monotemp_model"], "ckpt_model_path": mcfg["paths"]["ckpt_model_path"]},
+    }
+    json.dump(info, open(path_json, "w"), indent=1)
+    print(f"  glue: loss {loss.item():.6f} grad-norm {float(gn):.6f}, {len(info['state_dict_keys'])} state-dict keys")
+
+
+def main():
+    install_stubs()
+    slicing = {}
+    gen_slicing(slicing)
+    json.dump(slicing, open(os.path.join(HERE, "slicing_grids.json"), "w"))
+    windows = []
+    gen_windows(slicing, windows)
+    json.dump(windows, open(os.path.join(HERE, "write_windows.json"), "w"))
+    gen_convert(os.path.join(HERE, "convert.npz"))
+    gen_glue(os.path.join(HERE, "glue.json"), os.path.join(HERE, "glue_unet64.npz"))
+
+
+if __name__ == "__main__":
+    main()

@@ -46,9 +46,10 @@ def test_probe_mfma_layout(cuda, lib):
     g = torch.Generator().manual_seed(0)
     A = torch.randint(-4, 5, (32, 16), generator=g).float()
     Bm = torch.randint(-4, 5, (16, 32), generator=g).float()
+    Ad, Bd = A.to(cuda), Bm.to(cuda)
     for use_f32 in (0, 1):
         D = torch.zeros(32, 32, device=cuda)
-        L.check(lib.ffa_probe_mfma(A.to(cuda).data_ptr(), Bm.to(cuda).data_ptr(), D.data_ptr(), use_f32,
+        L.check(lib.ffa_probe_mfma(Ad.data_ptr(), Bd.data_ptr(), D.data_ptr(), use_f32,
                                    torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         assert torch.equal(D.cpu(), A @ Bm), f"MFMA lane map assumption broken (f32={use_f32})"
@@ -58,7 +59,8 @@ def test_probe_tr16_layout(cuda, lib):
     from flairhip import lib as L
     src = torch.arange(64 * 64, dtype=torch.int32).to(torch.int16)
     dst = torch.zeros(64 * 4, dtype=torch.int16, device=cuda)
-    L.check(lib.ffa_probe_tr16(src.to(cuda).data_ptr(), dst.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    srcd = src.to(cuda)
+    L.check(lib.ffa_probe_tr16(srcd.data_ptr(), dst.data_ptr(), torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     got = dst.cpu().view(64, 4).numpy()
     s = src.view(64, 64).numpy()
@@ -279,7 +281,9 @@ def test_maxpool(cuda, dtype, H, W):
     torch.cuda.synchronize()
     assert torch.equal(from_nhwc(y, C), y_ref.detach())
     err = (from_nhwc(dx, C) - xq.grad).abs().max().item()
-    assert err <= (1e-6 if dtype == torch.float32 else 0.02), f"maxpool bwd routes ties differently: {err}"
+    # bf16: up to four window gradients are summed in f32 and rounded once on store
+    lim = 1e-6 if dtype == torch.float32 else 2 ** -7 * float(xq.grad.abs().max())
+    assert err <= lim, f"maxpool bwd routes ties differently: {err}"
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])

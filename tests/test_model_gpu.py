@@ -1,0 +1,141 @@
+"""Whole-path parity (GPU): the HIP U-Net behind the FLAIR_HUB_Model / SegmentationTask API against the
+CPU oracle (oracle/unet_resnet34.py = the torch-CPU fp32 ops the reference reaches through smp).
+
+North-star bar: per-pixel logits within 1e-4 (fp32 mode) and identical per-pixel argmax; the bf16 mode is
+gated on argmax agreement and on a relative logit-error budget.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import MOD, TASK, make_pair
+
+pytestmark = pytest.mark.gpu
+
+WEIGHTS = torch.tensor([1.0] * 15 + [0.0] * 4)
+
+
+def _inputs(B, H, W, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 5, H, W, generator=g)
+    t = torch.randint(0, 19, (B, H, W), generator=g)
+    return x, t
+
+
+def _oracle_step(oracle, x, t, train):
+    oracle.train(train)
+    logits = oracle(x)
+    loss = F.cross_entropy(logits, t, weight=WEIGHTS)
+    return logits, loss
+
+
+@pytest.mark.parametrize("train", [False, True], ids=["eval", "train"])
+def test_fp32_logits_and_argmax_match_oracle(cuda, train):
+    task, oracle, cfg = make_pair(precision="fp32")
+    x, t = _inputs(2, 128, 96)
+    with torch.no_grad():
+        ref, _ = _oracle_step(oracle, x, t, train)
+    task.train(train)
+    with torch.no_grad():
+        out, _ = task.model({MOD: x.to(cuda), TASK: t.to(cuda)})
+    got = out[TASK].float().cpu()
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item()
+    assert err <= 1e-4 * max(1.0, ref.abs().max().item()), f"logit error {err}"
+    agree = (got.argmax(1) == ref.argmax(1)).float().mean().item()
+    assert agree >= 0.9999, f"argmax agreement {agree}"
+
+
+def test_fp32_training_step_matches_oracle(cuda):
+    task, oracle, cfg = make_pair(precision="fp32")
+    x, t = _inputs(2, 64, 96, seed=3)
+    oracle.train()
+    ref_logits, ref_loss = _oracle_step(oracle, x, t, True)
+    ref_loss.backward()
+    task.train()
+    batch = {MOD: x.to(cuda), TASK: t.to(cuda)}
+    loss, preds, targets = task.step(batch, training=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref_loss.item()) <= 2e-5 * max(1.0, abs(ref_loss.item()))
+    assert torch.equal(targets[TASK].cpu().long(), t)
+    agree = (preds[TASK].cpu().long() == ref_logits.argmax(1)).float().mean().item()
+    assert agree >= 0.9999
+    # every parameter gradient, compared by relative L2 error (conv, BN affine, head bias)
+    osd = dict(oracle.named_parameters())
+    worst = 0.0
+    for name, p in task.model.named_parameters():
+        if name.startswith("fusion_handler."):
+            assert p.grad is None
+            continue
+        if name.startswith("encoders."):
+            ok = "encoder." + name.split(".seg_model.", 1)[1]
+        else:
+            ok = name.split(".seg_model.", 1)[1]
+        rg = osd[ok].grad
+        rel = ((p.grad.cpu() - rg).norm() / (rg.norm() + 1e-12)).item()
+        worst = max(worst, rel)
+        assert rel <= 2e-3, f"{name}: relative grad error {rel}"
+    # BatchNorm running statistics were updated identically
+    o_buf = dict(oracle.named_buffers())
+    sd = task.model.state_dict()
+    for k, v in o_buf.items():
+        pk = ("encoders.%s.seg_model." % MOD + k[len("encoder."):]) if k.startswith("encoder.") else (
+            "main_decoders.%s.seg_model." % TASK + k)
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[pk]) == int(v)
+        else:
+            assert torch.allclose(sd[pk].cpu(), v, rtol=1e-4, atol=1e-5), k
+
+
+def test_bf16_argmax_agreement_and_error_budget(cuda):
+    task, oracle, cfg = make_pair(precision="bf16")
+    x, t = _inputs(2, 128, 128, seed=5)
+    oracle.eval()
+    with torch.no_grad():
+        ref = oracle(x)
+    task.eval()
+    with torch.no_grad():
+        out, _ = task.model({MOD: x.to(cuda), TASK: t.to(cuda)})
+    got = out[TASK].float().cpu()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    agree = (got.argmax(1) == ref.argmax(1)).float().mean().item()
+    assert rel <= 0.03, f"bf16 relative logit error {rel}"
+    assert agree >= 0.97, f"bf16 argmax agreement {agree}"
+
+
+def test_bf16_training_reduces_loss(cuda):
+    task, oracle, cfg = make_pair(precision="bf16")
+    x, t = _inputs(4, 64, 64, seed=7)
+    batch = {MOD: x.to(cuda), TASK: t.to(cuda)}
+    task.train()
+    opt = torch.optim.AdamW(task.model.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(8):
+        loss, _, _ = task.step(batch, training=True)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(l == l for l in losses)
+    assert losses[-1] < losses[0] * 0.9, losses
+
+
+def test_onehot_targets_and_predict_step(cuda):
+    task, oracle, cfg = make_pair(precision="fp32")
+    x, t = _inputs(1, 64, 64, seed=9)
+    onehot = F.one_hot(t, 19).permute(0, 3, 1, 2).float().contiguous()
+    task.eval()
+    with torch.no_grad():
+        l1, p1, t1 = task.step({MOD: x.to(cuda), TASK: onehot.to(cuda)})
+        l2, p2, t2 = task.step({MOD: x.to(cuda), TASK: t.to(cuda)})
+        pred = task.predict_step({MOD: x.to(cuda), TASK: t.to(cuda)})
+    assert l1.item() == l2.item() and torch.equal(t1[TASK], t2[TASK])
+    assert torch.equal(pred[f"preds_{TASK}"], p1[TASK])
+
+
+def test_product_path_rejects_cpu_tensors(cuda):
+    task, oracle, cfg = make_pair(precision="fp32")
+    x, t = _inputs(1, 32, 32)
+    with pytest.raises(RuntimeError):
+        task.model({MOD: x, TASK: t})

@@ -1,0 +1,233 @@
+"""CPU suite (no GPU): pins the oracle AND the host-side product code against fixtures produced by the
+reference's own code (tests/golden/gen_goldens.py ran /root/reference with stand-ins for its absent
+third-party imports).  Bit-exact for the float64 tile bookkeeping, exact for integer outputs."""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import MOD, ROOT, TASK
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def fh(s):
+    return float.fromhex(s)
+
+
+class RasterInfo:
+    """attribute-only raster (no pixel array) for the slicing API"""
+
+    def __init__(self, left, top, res, height, width):
+        from flair_zonal_detection.raster import BoundingBox
+        self.res = (res, res)
+        self.shape = (height, width)
+        self.height, self.width = height, width
+        self.crs = "EPSG:2154"
+        # rasterio.transform.array_bounds arithmetic
+        self.bounds = BoundingBox(left, (height * -res) + top, (width * res) + left, top)
+
+
+@pytest.fixture(scope="module")
+def grids():
+    return json.load(open(os.path.join(GOLD, "slicing_grids.json")))
+
+
+def _zone_of(sc):
+    r = sc["raster"]
+    ras = RasterInfo(r["left"], r["top"], r["res"], r["height"], r["width"])
+    if sc["zone"] is None:
+        return ras, None
+    return ras, tuple(fh(v) for v in sc["zone"])
+
+
+def test_goldens_cover_the_edge_cases(grids):
+    assert grids["bdortho_5km_full"]["n_tiles"] == 58 * 58  # 25000 px / 432 px stride, clamped last row / column
+    assert grids["no_overlap"]["n_tiles"] == 0
+    assert grids["small_single_tile"]["n_tiles"] == 1
+
+
+@pytest.mark.parametrize("name", ["bdortho_5km_full", "odd_origin_crop", "small_single_tile", "exact_multiple",
+                                  "coarse_res_margin0", "res_rounding_1p5"])
+def test_oracle_slicing_is_bit_exact(grids, name):
+    from oracle.tile_bookkeeping import slice_tiles
+    sc = grids[name]
+    ras, zone = _zone_of(sc)
+    tiles = slice_tiles(zone, tuple(ras.bounds), sc["patch"], sc["margin"], sc["reference_resolution"])
+    assert len(tiles) == sc["n_tiles"]
+    for got, exp in zip(tiles, sc["tiles"]):
+        assert got["id"] == exp["id"]
+        for k in ("left", "bottom", "right", "top"):
+            assert got[k].hex() == exp[k], (name, exp["id"], k)
+        if "box" in exp:
+            assert [v.hex() for v in got["box"]] == exp["box"]
+
+
+@pytest.mark.parametrize("name", ["bdortho_5km_full", "odd_origin_crop", "small_single_tile", "exact_multiple",
+                                  "coarse_res_margin0", "res_rounding_1p5", "no_overlap"])
+def test_product_slicing_is_bit_exact(grids, name, lib):
+    """libflairhip's ffa_slice_grid behind flair_zonal_detection.slicing.generate_patches_from_reference
+    (host code: runs without a GPU)."""
+    from flair_zonal_detection.slicing import generate_patches_from_reference
+    sc = grids[name]
+    r = sc["raster"]
+    ras = RasterInfo(r["left"], r["top"], r["res"], r["height"], r["width"])
+    cfg = {"img_pixels_detection": sc["patch"], "margin": sc["margin"], "output_path": "/tmp", "output_name": "golden",
+           "reference_modality": MOD, "reference_resolution": sc["reference_resolution"]}
+    if sc["no_overlap"]:
+        zone = (r["left"] - 1000.0, r["top"] + 500.0, r["left"] - 900.0, r["top"] + 600.0)
+    elif sc["crop"] is None:
+        zone = None
+    else:  # a geozone whose bounding box falls inside the crop window's outermost pixels
+        c0, r0, c1, r1 = sc["crop"]
+        res = r["res"]
+        zone = (r["left"] + (c0 + 0.4) * res, r["top"] - (r1 - 0.4) * res, r["left"] + (c1 - 0.4) * res,
+                r["top"] - (r0 + 0.4) * res)
+    df = generate_patches_from_reference(cfg, ras, zone)
+    assert len(df) == sc["n_tiles"]
+    if not len(df):
+        return
+    assert list(df.columns)[:12] == ["id", "input_id", "output_id", "job_done", "left", "bottom", "right", "top",
+                                     "left_o", "bottom_o", "right_o", "top_o"]
+    assert [df["left_o"][0].hex(), df["bottom_o"][0].hex(), df["right_o"][0].hex(), df["top_o"][0].hex()] == sc["zone"]
+    for i, exp in enumerate(sc["tiles"]):
+        row = df.iloc[i]
+        assert row["id"] == exp["id"]
+        for k in ("left", "bottom", "right", "top"):
+            assert float(row[k]).hex() == exp[k], (name, exp["id"], k)
+        if "box" in exp:
+            g = row["geometry"]
+            b = g.bounds if hasattr(g, "bounds") else g
+            assert [float(v).hex() for v in b] == exp["box"]
+
+
+def test_write_windows_match_reference(grids, lib):
+    from flairhip import ops
+    from oracle.tile_bookkeeping import write_window
+    cases = json.load(open(os.path.join(GOLD, "write_windows.json")))
+    n = 0
+    for case in cases:
+        sc = grids[case["scenario"]]
+        r = sc["raster"]
+        ras = RasterInfo(r["left"], r["top"], r["res"], r["height"], r["width"])
+        out_res = fh(case["out_res"])
+        keep = sc["patch"] - 2 * sc["margin"]
+        scale = sc["reference_resolution"] / out_res
+        pred = keep if abs(scale - 1) < 1e-9 else int(round(keep * scale))
+        written = iter(zip(case["windows"], case["shapes"]))
+        for idx in case["tile_indices"]:
+            t = sc["tiles"][idx]
+            o = write_window(fh(t["left"]), fh(t["top"]), tuple(ras.bounds), out_res, pred, pred)
+            w = ops.write_window(fh(t["left"]), fh(t["top"]), tuple(ras.bounds), out_res, pred, pred)
+            assert (w.col_off, w.row_off, w.width, w.height, bool(w.skip)) == o
+            if o[4]:
+                continue
+            win, shape = next(written)
+            assert list(o[:4]) == win and shape == [o[3], o[2]]
+            n += 1
+    assert n > 300
+
+
+def test_oracle_convert_matches_reference():
+    from oracle.tile_bookkeeping import convert
+    d = np.load(os.path.join(GOLD, "convert.npz"))
+    assert np.array_equal(convert(d["logits"], "argmax"), d["argmax"])
+    assert np.array_equal(convert(d["logits"], "class_prob"), d["class_prob"])
+    with pytest.raises(ValueError):
+        convert(d["logits"], "logits")
+
+
+@pytest.fixture(scope="module")
+def glue():
+    return json.load(open(os.path.join(GOLD, "glue.json")))
+
+
+def test_state_dict_keys_and_loss_weights_match_reference(glue):
+    from flairhip.configs import unet_resnet34_config
+    from flair_hub.tasks.module_setup import FLAIRLosses, build_segmentation_module
+    from oracle.tile_bookkeeping import flair_loss_weights
+    cfg = unet_resnet34_config(in_channels=5, precision="fp32")
+    task = build_segmentation_module(cfg, {MOD: 64}, "train")
+    assert sorted(task.state_dict().keys()) == glue["state_dict_keys"]
+    w = FLAIRLosses(cfg).get_default_weights(TASK)
+    assert [float(v) for v in w] == glue["loss_weights"]
+    assert list(flair_loss_weights(cfg["labels_configs"][TASK])) == glue["loss_weights"]
+
+
+def test_zonal_config_expansion_matches_reference(glue):
+    import yaml
+    from flair_zonal_detection.inference import initialize_geometry_and_resolutions
+    from flair_zonal_detection.model_utils import compute_patch_sizes, prepare_model_config
+    from oracle.tile_bookkeeping import patch_size
+    z = glue["zonal"]
+    cfg = yaml.safe_load(open(os.path.join(GOLD, "zonal_config.yaml")))
+    ras = RasterInfo(651992.36, 6860417.84, 0.2, 6173, 7311)
+    cfg["modalities"][MOD]["input_img_path"] = ras
+    cfg = initialize_geometry_and_resolutions(cfg)
+    for k in ("reference_resolution", "reference_modality", "tile_size_m", "margin_size_m", "image_bounds"):
+        assert cfg[k] == z[k], k
+    assert compute_patch_sizes(cfg) == z["patch_sizes"]
+    assert patch_size(512, 0.2, 0.2) == z["patch_sizes"][MOD]
+    m = prepare_model_config(cfg)
+    assert m["labels"] == z["labels"]
+    assert len(m["labels_configs"][TASK]["value_name"]) == z["n_classes"]
+    assert m["modalities"]["inputs_channels"] == z["inputs_channels"]
+    assert m["modalities"]["aux_loss"] == z["aux_loss"]
+    assert m["modalities"]["pre_processings"] == z["pre_processings"]
+    assert m["models"]["monotemp_model"] == z["monotemp_model"]
+    assert m["paths"]["ckpt_model_path"] == z["ckpt_model_path"]
+
+
+def test_oracle_reproduces_reference_glue_outputs(glue):
+    """oracle conv stack + seeded weights == what the reference's FLAIR_HUB_Model / SegmentationTask computed
+    around the same conv stack (eval logits, predict_step argmax)."""
+    import torch.nn.functional as F
+    from helpers import oracle_to_product_keys
+    from oracle.seeded_weights import checksum, fill_state_dict
+    from oracle.unet_resnet34 import UnetResNet34
+    d = np.load(os.path.join(GOLD, "glue_unet64.npz"))
+    from flairhip.configs import unet_resnet34_config
+    from flair_hub.tasks.module_setup import build_segmentation_module
+    cfg = unet_resnet34_config(in_channels=5, precision="fp32")
+    task = build_segmentation_module(cfg, {MOD: 64}, "train")
+    sd = fill_state_dict(task.model.state_dict())
+    assert abs(checksum(sd) - glue["weights_checksum"]) <= 1e-6 * glue["weights_checksum"]
+    oracle = UnetResNet34(5, 19)
+    to_oracle = oracle_to_product_keys({k: k for k in oracle.state_dict()})  # product key -> oracle key
+    oracle.load_state_dict({to_oracle[k]: v for k, v in sd.items() if k in to_oracle})
+    x, t = torch.from_numpy(d["x"]), torch.from_numpy(d["t"]).long()
+    oracle.eval()
+    with torch.no_grad():
+        logits = oracle(x)
+    assert np.abs(logits.numpy() - d["logits_eval"]).max() <= 1e-5
+    assert np.array_equal(logits.argmax(1).numpy().astype(np.uint8), d["preds_eval"])
+    oracle.train()
+    out = oracle(x)
+    loss = F.cross_entropy(out, t, weight=torch.tensor(glue["loss_weights"]))
+    assert abs(loss.item() - fh(glue["train_loss"])) <= 1e-5
+    assert (out.argmax(1).numpy().astype(np.uint8) == d["preds_train"]).mean() > 0.9999
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from flairhip import lib as L
+    header = open(os.path.join(ROOT, "include", "flairhip.h")).read()
+    declared = set(re.findall(r"\b(ffa_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 30
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/flairhip.h but not exported"
+        assert name in L.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(L.SIGNATURES) <= declared
+    assert lib.ffa_target_arch() == b"gfx950"
+
+
+def test_argument_errors_are_reported_not_thrown(lib):
+    from flairhip import lib as L
+    rc = lib.ffa_conv2d(0, None, None, None, None, None, 1, 8, 8, 16, 8, 8, 16, 32, 32, 3, 3, 1, 1, 1, 0, None)
+    assert rc == -1 and b"null" in lib.ffa_last_error()
+    assert lib.ffa_slice_grid(0.0, 0.0, 10.0, 10.0, 0.0, 0.0, 64, 32, 0.2, None, 0) == -1
+    with pytest.raises(L.FlairHipError):
+        L.check(rc, "conv2d")
