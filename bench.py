@@ -100,7 +100,12 @@ def cpu_baseline(budget_s: float = 25.0):
     """The oracle's training step on the host cores (fp32, NCHW, eager, AdamW): B=2 tiles per step."""
     import torch.nn.functional as F
     from oracle.unet_resnet34 import UnetResNet34
-    threads = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host: 16 cores (more threads than that oversubscribe the cgroup)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))
     torch.set_num_threads(threads)
     torch.manual_seed(2025)
     model = UnetResNet34(5, 19).train()

@@ -18,7 +18,7 @@
 struct WgradArgs {
   const void* x;
   const void* dy;
-  float* slabs;  // [nsplit][CoT][KH*KW][CiT]
+  float* slabs;  // [nsplit * WK][CoT][KH*KW][CiT]
   int B, Hi, Wi, Ci;
   int Ho, Wo, Co;
   int pad;
@@ -27,9 +27,11 @@ struct WgradArgs {
   int CoT, CiT;
 };
 
-template <int KH, int KW, int STRIDE, int RG, int WCO, int WCI, int TH, int TW, int EB>
+// WCO x WCI waves own distinct (co, ci) sub-tiles; WK further waves split the tile's k-steps (pixels) and
+// write their own partial slab, which keeps 256-thread blocks (fast staging) for layers with few channels.
+template <int KH, int KW, int STRIDE, int RG, int WCO, int WCI, int WK, int TH, int TW, int EB>
 struct WgradGeom {
-  static constexpr int NTHR = 64 * WCO * WCI;
+  static constexpr int NTHR = 64 * WCO * WCI * WK;
   static constexpr int NPX = TH * TW;
   static constexpr bool ONE = (KH == 1 && KW == 1);
   static constexpr int LS = ONE ? 1 : STRIDE;
@@ -47,7 +49,9 @@ struct WgradGeom {
   static constexpr int IN_PIECES = WCI * IH * IW * PARTS;
   static constexpr int NDP = (DY_PIECES + NTHR - 1) / NTHR;
   static constexpr int NIP = (IN_PIECES + NTHR - 1) / NTHR;
+  static constexpr int KSTEPS = NPX / 16;
   static_assert(TW % 16 == 0, "a 16-pixel k-step must stay inside one tile row");
+  static_assert(KSTEPS % WK == 0, "k-steps must divide over the k-split waves");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -58,10 +62,10 @@ __device__ __forceinline__ ffa_s16x4 lds_read_tr16(const unsigned char* p) {
       (__attribute__((address_space(3))) ffa_s16x4*)(const_cast<unsigned char*>(p)));
 }
 
-template <typename T, int KH, int KW, int STRIDE, int RG, int WCO, int WCI, int TH, int TW>
-__global__ void __launch_bounds__(64 * WCO * WCI) conv_wgrad_kernel(WgradArgs a) {
+template <typename T, int KH, int KW, int STRIDE, int RG, int WCO, int WCI, int WK, int TH, int TW>
+__global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1)) conv_wgrad_kernel(WgradArgs a) {
   constexpr int EB = ElemTraits<T>::kBytes;
-  using G = WgradGeom<KH, KW, STRIDE, RG, WCO, WCI, TH, TW, EB>;
+  using G = WgradGeom<KH, KW, STRIDE, RG, WCO, WCI, WK, TH, TW, EB>;
   __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
   unsigned char* sDy = smem;
   unsigned char* sIn = smem + G::DY_BYTES;
@@ -69,7 +73,8 @@ __global__ void __launch_bounds__(64 * WCO * WCI) conv_wgrad_kernel(WgradArgs a)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wco = wave / WCI, wci = wave % WCI;
+  const int wk = wave / (WCO * WCI);
+  const int wco = (wave / WCI) % WCO, wci = wave % WCI;
 
   int tb = blockIdx.x;
   const int rg = tb % G::NRG;
@@ -96,54 +101,72 @@ __global__ void __launch_bounds__(64 * WCO * WCI) conv_wgrad_kernel(WgradArgs a)
   const unsigned char* dyPlane = sDy + wco * (G::NPX * G::ROWB);
   const unsigned char* inPlane = sIn + wci * (G::IH * G::IW * G::ROWB);
 
-  for (int pt = split; pt < a.npt; pt += a.nsplit) {
-    const int tx = pt % a.tiles_x;
-    const int t2 = pt / a.tiles_x;
-    const int ty = t2 % a.tiles_y;
-    const int b = t2 / a.tiles_y;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * STRIDE - a.pad + rg * RG;
-    const int ix0 = ox0 * STRIDE - a.pad;
+  // staging registers: the NEXT tile's global loads are issued before the MFMAs of the current tile
+  ffa_u32x4 dreg[G::NDP];
+  ffa_u32x4 ireg[G::NIP];
 
+#define FFA_WG_LOAD(pt_)                                                                                       \
+  {                                                                                                            \
+    const int tx_ = (pt_) % a.tiles_x;                                                                         \
+    const int t2_ = (pt_) / a.tiles_x;                                                                         \
+    const int ty_ = t2_ % a.tiles_y;                                                                           \
+    const int b_ = t2_ / a.tiles_y;                                                                            \
+    const int oy0_ = ty_ * TH, ox0_ = tx_ * TW;                                                                \
+    const int iy0_ = oy0_ * STRIDE - a.pad + rg * RG;                                                          \
+    const int ix0_ = ox0_ * STRIDE - a.pad;                                                                    \
+    _Pragma("unroll") for (int k = 0; k < G::NDP; ++k) {                                                       \
+      const int i = tid + k * G::NTHR;                                                                         \
+      const int part = i % G::PARTS;                                                                           \
+      const int n = (i / G::PARTS) % G::NPX;                                                                   \
+      const int plane = i / (G::PARTS * G::NPX);                                                               \
+      const int oy = oy0_ + n / TW, ox = ox0_ + n % TW;                                                        \
+      const int c = co0 + plane * 32 + part * (16 / EB);                                                       \
+      ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};                                                                 \
+      if (i < G::DY_PIECES && oy < a.Ho && ox < a.Wo && c < a.Co)                                              \
+        v = *reinterpret_cast<const ffa_u32x4*>(dy_b +                                                         \
+                                                (((size_t)(b_ * a.Ho + oy) * a.Wo + ox) * a.Co + c) * EB);     \
+      dreg[k] = v;                                                                                             \
+    }                                                                                                          \
+    _Pragma("unroll") for (int k = 0; k < G::NIP; ++k) {                                                       \
+      const int i = tid + k * G::NTHR;                                                                         \
+      const int part = i % G::PARTS;                                                                           \
+      const int q = (i / G::PARTS) % (G::IH * G::IW);                                                          \
+      const int plane = i / (G::PARTS * G::IH * G::IW);                                                        \
+      const int vy = iy0_ + (q / G::IW) * G::GSTEP;                                                            \
+      const int vx = ix0_ + (q % G::IW) * G::GSTEP;                                                            \
+      const int c = ci0 + plane * 32 + part * (16 / EB);                                                       \
+      ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};                                                                 \
+      if (i < G::IN_PIECES && vy >= 0 && vx >= 0 && vy < a.Hi && vx < a.Wi && c < a.Ci)                        \
+        v = *reinterpret_cast<const ffa_u32x4*>(x_b +                                                          \
+                                                (((size_t)(b_ * a.Hi + vy) * a.Wi + vx) * a.Ci + c) * EB);     \
+      ireg[k] = v;                                                                                             \
+    }                                                                                                          \
+  }
+#define FFA_WG_STORE()                                                                          \
+  {                                                                                             \
+    _Pragma("unroll") for (int k = 0; k < G::NDP; ++k) {                                        \
+      const int i = tid + k * G::NTHR;                                                          \
+      if (G::DY_PIECES % G::NTHR == 0 || i < G::DY_PIECES)                                      \
+        *reinterpret_cast<ffa_u32x4*>(sDy + (size_t)i * 16) = dreg[k];                          \
+    }                                                                                           \
+    _Pragma("unroll") for (int k = 0; k < G::NIP; ++k) {                                        \
+      const int i = tid + k * G::NTHR;                                                          \
+      if (G::IN_PIECES % G::NTHR == 0 || i < G::IN_PIECES)                                      \
+        *reinterpret_cast<ffa_u32x4*>(sIn + (size_t)i * 16) = ireg[k];                          \
+    }                                                                                           \
+  }
+
+  int pt = split;
+  if (pt < a.npt) FFA_WG_LOAD(pt)
+  for (; pt < a.npt; pt += a.nsplit) {
     __syncthreads();  // previous tile's fragment reads are done
-    // ---- stage dy tile: [plane][pixel][32 ch]
-#pragma unroll 4
-    for (int k = 0; k < G::NDP; ++k) {
-      const int i = tid + k * G::NTHR;
-      if (i < G::DY_PIECES) {
-        const int part = i % G::PARTS;
-        const int n = (i / G::PARTS) % G::NPX;
-        const int plane = i / (G::PARTS * G::NPX);
-        const int oy = oy0 + n / TW, ox = ox0 + n % TW;
-        const int c = co0 + plane * 32 + part * (16 / EB);
-        ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};
-        if (oy < a.Ho && ox < a.Wo && c < a.Co)
-          v = *reinterpret_cast<const ffa_u32x4*>(dy_b + (((size_t)(b * a.Ho + oy) * a.Wo + ox) * a.Co + c) * EB);
-        *reinterpret_cast<ffa_u32x4*>(sDy + (plane * G::NPX + n) * G::ROWB + part * 16) = v;
-      }
-    }
-    // ---- stage input halo: [plane][halo pixel][32 ch]
-#pragma unroll 4
-    for (int k = 0; k < G::NIP; ++k) {
-      const int i = tid + k * G::NTHR;
-      if (i < G::IN_PIECES) {
-        const int part = i % G::PARTS;
-        const int q = (i / G::PARTS) % (G::IH * G::IW);
-        const int plane = i / (G::PARTS * G::IH * G::IW);
-        const int vy = iy0 + (q / G::IW) * G::GSTEP;
-        const int vx = ix0 + (q % G::IW) * G::GSTEP;
-        const int c = ci0 + plane * 32 + part * (16 / EB);
-        ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};
-        if (vy >= 0 && vx >= 0 && vy < a.Hi && vx < a.Wi && c < a.Ci)
-          v = *reinterpret_cast<const ffa_u32x4*>(x_b + (((size_t)(b * a.Hi + vy) * a.Wi + vx) * a.Ci + c) * EB);
-        *reinterpret_cast<ffa_u32x4*>(sIn + (plane * (G::IH * G::IW) + q) * G::ROWB + part * 16) = v;
-      }
-    }
+    FFA_WG_STORE()    // piece i lives at byte i*16: [plane][pixel][32 ch] is linear in the piece index
     __syncthreads();
+    if (pt + a.nsplit < a.npt) FFA_WG_LOAD(pt + a.nsplit)
 
-    // ---- K loop over the tile's pixels, 16 per step
+    // ---- K loop over the tile's pixels, 16 per step; wave wk takes steps wk, wk + WK, ...
 #pragma unroll 1
-    for (int ks = 0; ks < G::NPX / 16; ++ks) {
+    for (int ks = wk; ks < G::KSTEPS; ks += WK) {
       const int n0 = ks * 16;
       const int py = n0 / TW, px0 = n0 % TW;
       if constexpr (EB == 2) {
@@ -194,44 +217,63 @@ __global__ void __launch_bounds__(64 * WCO * WCI) conv_wgrad_kernel(WgradArgs a)
       }
     }
   }
+#undef FFA_WG_LOAD
+#undef FFA_WG_STORE
 
   // ---- write the partial slab: D[co][ci], lane column = ci, rows co = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int ci = ci0 + wci * 32 + (lane & 31);
   const int co_w = co0 + wco * 32;
   const size_t taps_total = (size_t)KH * KW;
+  const size_t slab = (size_t)split * WK + wk;
 #pragma unroll
   for (int t = 0; t < G::TAPS; ++t) {
     const int tapg = rg * G::TAPS + t;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co_w + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      a.slabs[(((size_t)split * a.CoT + co) * taps_total + tapg) * a.CiT + ci] = acc[t][r];
+      a.slabs[((slab * a.CoT + co) * taps_total + tapg) * a.CiT + ci] = acc[t][r];
     }
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int nsplit, int CoT,
-                                    int CiT, int Co, int Ci, int taps, int accumulate) {
-  // dw is OIHW [Co][Ci][taps]; consecutive threads take consecutive ci of one (co, tap) so the slab
-  // reads are coalesced
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int nsplit, int CoT, int CiT, int Co,
+                    int Ci, int taps, int accumulate) {
+  // dw is OIHW [Co][Ci][taps].  256 threads = 8 split lanes x 32 consecutive (co, tap, ci) outputs: the slab
+  // reads of a lane are coalesced along ci, lane l adds splits l, l+8, ... and lane 0 adds the 8 lane sums in
+  // order -> fixed summation order, and no thread walks hundreds of dependent L2 round trips.
+  __shared__ float sh[8][33];
+  const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const long long total = (long long)Co * taps * Ci;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % Ci);
-    const long long t2 = i / Ci;
-    const int tap = (int)(t2 % taps);
-    const int co = (int)(t2 / taps);
+  for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {
+    const long long i = base + ol;
+    const bool valid = i < total;
+    int ci = 0, tap = 0, co = 0;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slabs[(((size_t)k * CoT + co) * taps + tap) * CiT + ci];
-    float* dst = dw + ((size_t)co * Ci + ci) * taps + tap;
-    *dst = accumulate ? (*dst + s) : s;
+    if (valid) {
+      ci = (int)(i % Ci);
+      const long long t2 = i / Ci;
+      tap = (int)(t2 % taps);
+      co = (int)(t2 / taps);
+      for (int k = sl; k < nsplit; k += 8) s += slabs[(((size_t)k * CoT + co) * taps + tap) * CiT + ci];
+    }
+    sh[sl][ol] = s;
+    __syncthreads();
+    if (sl == 0 && valid) {
+      float t = 0.f;
+#pragma unroll
+      for (int l = 0; l < 8; ++l) t += sh[l][ol];
+      float* dst = dw + ((size_t)co * Ci + ci) * taps + tap;
+      *dst = accumulate ? (*dst + t) : t;
+    }
+    __syncthreads();
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 
 struct WgradPlan {
-  int wco, wci, th, tw, rg, nsplit, ncob, ncib, CoT, CiT, npt, tiles_x, tiles_y;
+  int wco, wci, wk, th, tw, rg, nsplit, ncob, ncib, CoT, CiT, npt, tiles_x, tiles_y;
 };
 
 static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, int B, int Ho, int Wo, WgradPlan* p) {
@@ -240,19 +282,21 @@ static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, in
   const bool one = (kh == 1 && kw == 1 && (stride == 1 || stride == 2));
   const bool stem = (kh == 7 && kw == 7 && stride == 2);
   if (!(s1 || s2 || one || stem)) return false;
+  const bool f32 = (dtype == FFA_F32);
   p->rg = stem ? 1 : kh;
-  p->tw = (Wo >= 32) ? 32 : 16;
-  p->th = (Wo >= 32) ? 8 : 16;
-  if (!s1) {  // stride-2 halos are 4x larger and only the 8x16 tile is instantiated for these shapes
+  p->wk = 1;
+  if (s1) {
+    p->tw = (Wo >= 32) ? 32 : 16;
+    p->th = (Wo >= 32) ? 4 : 8;
+    p->wco = (Co > 32) ? 2 : 1;
+    p->wci = (Ci > 32 && !f32) ? 2 : 1;  // f32 planes are twice as large: one ci plane per block
+    if (!f32) p->wk = 4 / (p->wco * p->wci);
+  } else {  // only the shapes the network needs are instantiated for the strided / 1x1 / stem kernels
     p->tw = 16;
-    p->th = 8;
-  }
-  p->wco = (Co > 32) ? 2 : 1;
-  p->wci = (Ci > 32) ? 2 : 1;
-  if (dtype == FFA_F32) p->wci = 1;  // f32 planes are twice as large; keep LDS under 160 KiB
-  if (!s1) {                         // only the shapes the network needs are instantiated
+    p->th = stem ? 8 : 4;
     p->wco = 2;
-    p->wci = (dtype == FFA_F32 || stem) ? 1 : 2;
+    p->wci = (f32 || stem) ? 1 : 2;
+    if (stem && !f32) p->wk = 2;
   }
   p->ncob = ffa_cdiv(Co, 32 * p->wco);
   p->ncib = ffa_cdiv(Ci, 32 * p->wci);
@@ -262,7 +306,7 @@ static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, in
   p->tiles_y = ffa_cdiv(Ho, p->th);
   p->npt = B * p->tiles_x * p->tiles_y;
   const int tile_blocks = p->ncob * p->ncib * (kh / p->rg);
-  int ns = ffa_cdiv(768, tile_blocks);
+  int ns = ffa_cdiv(512, tile_blocks);  // ~2 blocks per CU; every split costs one f32 slab of HBM traffic
   if (ns > p->npt) ns = p->npt;
   if (ns < 1) ns = 1;
   p->nsplit = ns;
@@ -273,14 +317,14 @@ extern "C" long long ffa_conv_wgrad_workspace_bytes(int dtype, int kh, int kw, i
                                                     int Wo) {
   WgradPlan p;
   if (!wgrad_plan(dtype, kh, kw, stride, Co, Ci, B, Ho, Wo, &p)) return FFA_ERR_UNSUPPORTED;
-  return (long long)p.nsplit * p.CoT * kh * kw * p.CiT * (long long)sizeof(float);
+  return (long long)p.nsplit * p.wk * p.CoT * kh * kw * p.CiT * (long long)sizeof(float);
 }
 
-template <typename T, int KH, int KW, int STRIDE, int RG, int WCO, int WCI, int TH, int TW>
+template <typename T, int KH, int KW, int STRIDE, int RG, int WCO, int WCI, int WK, int TH, int TW>
 static void launch_wgrad_cfg(const WgradArgs& a, int nrg, hipStream_t stream) {
   dim3 grid(a.ncob * a.ncib * nrg, a.nsplit);
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW, STRIDE, RG, WCO, WCI, TH, TW>), grid, dim3(64 * WCO * WCI), 0,
-                     stream, a);
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW, STRIDE, RG, WCO, WCI, WK, TH, TW>), grid,
+                     dim3(64 * WCO * WCI * WK), 0, stream, a);
 }
 
 template <typename T>
@@ -288,33 +332,36 @@ static int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int kh, int kw, 
   constexpr bool F32 = (sizeof(T) == 4);
   const bool wide = (p.tw == 32);
   if (kh == 3 && stride == 1) {
-#define FFA_WG_S1(WCO_, WCI_)                                                        \
-  if (p.wco == WCO_ && p.wci == WCI_) {                                              \
-    if (wide) launch_wgrad_cfg<T, 3, 3, 1, 3, WCO_, WCI_, 8, 32>(a, 1, stream);      \
-    else launch_wgrad_cfg<T, 3, 3, 1, 3, WCO_, WCI_, 16, 16>(a, 1, stream);          \
-    return ffa_check_launch("conv_wgrad");                                           \
+#define FFA_WG_S1(WCO_, WCI_, WK_)                                                        \
+  if (p.wco == WCO_ && p.wci == WCI_ && p.wk == WK_) {                                    \
+    if (wide) launch_wgrad_cfg<T, 3, 3, 1, 3, WCO_, WCI_, WK_, 4, 32>(a, 1, stream);      \
+    else launch_wgrad_cfg<T, 3, 3, 1, 3, WCO_, WCI_, WK_, 8, 16>(a, 1, stream);           \
+    return ffa_check_launch("conv_wgrad");                                                \
   }
-    FFA_WG_S1(2, 1)
-    FFA_WG_S1(1, 1)
-    if constexpr (!F32) {
-      FFA_WG_S1(2, 2)
-      FFA_WG_S1(1, 2)
+    if constexpr (F32) {
+      FFA_WG_S1(2, 1, 1)
+      FFA_WG_S1(1, 1, 1)
+    } else {
+      FFA_WG_S1(2, 2, 1)
+      FFA_WG_S1(2, 1, 2)
+      FFA_WG_S1(1, 2, 2)
+      FFA_WG_S1(1, 1, 4)
     }
 #undef FFA_WG_S1
   } else if (kh == 3 && stride == 2) {
-    launch_wgrad_cfg<T, 3, 3, 2, 3, 2, F32 ? 1 : 2, 8, 16>(a, 1, stream);
+    launch_wgrad_cfg<T, 3, 3, 2, 3, 2, F32 ? 1 : 2, 1, 4, 16>(a, 1, stream);
     return ffa_check_launch("conv_wgrad");
   } else if (kh == 1 && stride == 2) {
-    launch_wgrad_cfg<T, 1, 1, 2, 1, 2, F32 ? 1 : 2, 8, 16>(a, 1, stream);
+    launch_wgrad_cfg<T, 1, 1, 2, 1, 2, F32 ? 1 : 2, 1, 4, 16>(a, 1, stream);
     return ffa_check_launch("conv_wgrad");
   } else if (kh == 1 && stride == 1) {
-    launch_wgrad_cfg<T, 1, 1, 1, 1, 2, F32 ? 1 : 2, 8, 16>(a, 1, stream);
+    launch_wgrad_cfg<T, 1, 1, 1, 1, 2, F32 ? 1 : 2, 1, 4, 16>(a, 1, stream);
     return ffa_check_launch("conv_wgrad");
   } else if (kh == 7) {
-    launch_wgrad_cfg<T, 7, 7, 2, 1, 2, 1, 8, 16>(a, 7, stream);
+    launch_wgrad_cfg<T, 7, 7, 2, 1, 2, 1, F32 ? 1 : 2, 8, 16>(a, 7, stream);
     return ffa_check_launch("conv_wgrad");
   }
-  ffa_set_error("conv_wgrad: no kernel for %dx%d stride %d waves %dx%d", kh, kw, stride, p.wco, p.wci);
+  ffa_set_error("conv_wgrad: no kernel for %dx%d stride %d waves %dx%dx%d", kh, kw, stride, p.wco, p.wci, p.wk);
   return FFA_ERR_UNSUPPORTED;
 }
 
@@ -332,7 +379,7 @@ extern "C" int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* d
     ffa_set_error("conv_wgrad: unsupported kernel %dx%d stride %d", kh, kw, stride);
     return FFA_ERR_UNSUPPORTED;
   }
-  const long long need = (long long)p.nsplit * p.CoT * kh * kw * p.CiT * (long long)sizeof(float);
+  const long long need = (long long)p.nsplit * p.wk * p.CoT * kh * kw * p.CiT * (long long)sizeof(float);
   if (workspace_bytes < need) {
     ffa_set_error("conv_wgrad: workspace too small (%lld < %lld)", workspace_bytes, need);
     return FFA_ERR_WORKSPACE;
@@ -349,10 +396,10 @@ extern "C" int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* d
                                : launch_wgrad<float>(a, p, kh, kw, stride, stream);
   if (rc != FFA_OK) return rc;
   const long long total = (long long)Co_real * kh * kw * Ci_real;
-  long long g = (total + 255) / 256;
-  if (g > 2048) g = 2048;
+  long long g = (total + 31) / 32;
+  if (g > 4096) g = 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)g), dim3(256), 0, stream, (const float*)workspace, dw_oihw,
-                     p.nsplit, p.CoT, p.CiT, Co_real, Ci_real, kh * kw, accumulate);
+                     p.nsplit * p.wk, p.CoT, p.CiT, Co_real, Ci_real, kh * kw, accumulate);
   return ffa_check_launch("wgrad_reduce");
 }
 

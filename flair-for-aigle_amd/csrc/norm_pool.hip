@@ -166,20 +166,48 @@ static int reduce_blocks(long long npix, int C) {
   return (int)g;
 }
 
-extern "C" long long ffa_bn_workspace_bytes(int C) { return (long long)FFA_MAX_PARTIALS * 2 * C * sizeof(float); }
+extern "C" long long ffa_bn_workspace_bytes(int C) {
+  // block partials [FFA_MAX_PARTIALS][2][C] + three per-channel coefficient vectors for the backward apply
+  return ((long long)FFA_MAX_PARTIALS * 2 * C + 4LL * C) * (long long)sizeof(float);
+}
 
-__global__ void bn_finalize_kernel(const float* __restrict__ ws, int nparts, double count, int C,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                                   float eps, float* __restrict__ scale, float* __restrict__ shift,
-                                   float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int p = 0; p < nparts; ++p) {
-    s += (double)ws[((long long)p * 2 + 0) * C + c];
-    q += (double)ws[((long long)p * 2 + 1) * C + c];
+// Fixed-order sum of the block partials ws[p][which][C]: 256 threads = 32 partial lanes x 8 channels; lane l
+// adds partials l, l+32, ... in double, lane 0 then adds the 32 lane sums in order.  (A single thread walking
+// 1024 partials is a 1024-deep chain of dependent L2 round trips: 190 us per call, measured.)
+#define FFA_FIN_THREADS 256
+__device__ __forceinline__ bool reduce_partials(const float* __restrict__ ws, int nparts, int C, int& c, double& s,
+                                                double& q) {
+  __shared__ double sh[2][32][8];
+  const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  c = blockIdx.x * 8 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    for (int p = lane; p < nparts; p += 32) {
+      a += (double)ws[((long long)p * 2 + 0) * C + c];
+      b += (double)ws[((long long)p * 2 + 1) * C + c];
+    }
   }
+  sh[0][lane][cl] = a;
+  sh[1][lane][cl] = b;
+  __syncthreads();
+  if (lane != 0 || c >= C) return false;
+  s = 0.0;
+  q = 0.0;
+  for (int l = 0; l < 32; ++l) {
+    s += sh[0][l][cl];
+    q += sh[1][l][cl];
+  }
+  return true;
+}
+
+__global__ void __launch_bounds__(FFA_FIN_THREADS)
+bn_finalize_kernel(const float* __restrict__ ws, int nparts, double count, int C, const float* __restrict__ gamma,
+                   const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+                   float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                   float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  int c;
+  double s, q;
+  if (!reduce_partials(ws, nparts, C, c, s, q)) return;
   const double mean = s / count;
   double var = q / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -220,8 +248,8 @@ extern "C" int ffa_bn_stats(int dtype, const void* x, long long npix, int C, con
   else
     hipLaunchKernelGGL((channel_reduce_kernel<float, StatOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
                        (const float*)x, (const float*)nullptr, (const float*)nullptr, nullptr, nullptr, ws, npix, C, 0);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ffa_cdiv(C, 128)), dim3(128), 0, stream, ws, nb, (double)npix, C, gamma,
-                     beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, rstd_out);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ffa_cdiv(C, 8)), dim3(FFA_FIN_THREADS), 0, stream, ws, nb, (double)npix,
+                     C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, rstd_out);
   return ffa_check_launch("bn_stats");
 }
 
@@ -255,10 +283,12 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ r
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec;
        i += (long long)gridDim.x * blockDim.x) {
     const int c0 = (int)(i % CG) * 8;
-    float v[8];
+    float v[8], sc[8], sh[8];
     ffa_load8<T>(x + i * 8, v);
+    ffa_load8<float>(scale + c0, sc);
+    ffa_load8<float>(shift + c0, sh);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = v[e] * scale[c0 + e] + shift[c0 + e];
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
     if (res) {
       float r[8];
       ffa_load8<T>(res + i * 8, r);
@@ -287,32 +317,41 @@ extern "C" int ffa_bn_apply(int dtype, const void* x, const void* residual, void
   return ffa_check_launch("bn_apply");
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ ws, int nparts, int C, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int p = 0; p < nparts; ++p) {
-    s += (double)ws[((long long)p * 2 + 0) * C + c];
-    q += (double)ws[((long long)p * 2 + 1) * C + c];
-  }
+// dgamma / dbeta from the block partials, plus the three per-channel coefficients of the apply pass:
+//   dx = gamma*rstd * (g - dbeta/N - xhat*dgamma/N) = kg*g + kx*x + k0
+//   kg = gamma*rstd, kx = -kg*rstd*dgamma/N, k0 = -kg*dbeta/N - kx*mean
+__global__ void __launch_bounds__(FFA_FIN_THREADS)
+bn_bwd_finalize_kernel(const float* __restrict__ ws, int nparts, int C, const float* __restrict__ gamma,
+                       const float* __restrict__ mean, const float* __restrict__ rstd, float inv_count,
+                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+  int c;
+  double s, q;
+  if (!reduce_partials(ws, nparts, C, c, s, q)) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)q;
+  if (coef) {
+    const float kg = (gamma ? gamma[c] : 1.f) * rstd[c];
+    const float kx = -kg * rstd[c] * (float)q * inv_count;
+    coef[c] = kg;
+    coef[C + c] = kx;
+    coef[2 * C + c] = -kg * (float)s * inv_count - kx * mean[c];
+  }
 }
 
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
-                                    const float* __restrict__ gamma, const float* __restrict__ mean,
-                                    const float* __restrict__ rstd, const float* __restrict__ dgamma,
-                                    const float* __restrict__ dbeta, T* __restrict__ dx, T* __restrict__ dres,
-                                    long long nvec, int C, int relu, float inv_count) {
+                                    const float* __restrict__ coef, T* __restrict__ dx, T* __restrict__ dres,
+                                    long long nvec, int C, int relu) {
   const int CG = C / 8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec;
        i += (long long)gridDim.x * blockDim.x) {
     const int c0 = (int)(i % CG) * 8;
-    float xv[8], gv[8];
+    float xv[8], gv[8], kg[8], kx[8], k0[8];
     ffa_load8<T>(x + i * 8, xv);
     ffa_load8<T>(dy + i * 8, gv);
+    ffa_load8<float>(coef + c0, kg);
+    ffa_load8<float>(coef + C + c0, kx);
+    ffa_load8<float>(coef + 2 * C + c0, k0);
     if (relu) {
       float yv[8];
       ffa_load8<T>(y + i * 8, yv);
@@ -322,12 +361,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
     if (dres) ffa_store8<T>(dres + i * 8, gv);
     float o[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = c0 + e;
-      const float xhat = (xv[e] - mean[c]) * rstd[c];
-      const float g = gamma ? gamma[c] : 1.f;
-      o[e] = g * rstd[c] * (gv[e] - dbeta[c] * inv_count - xhat * dgamma[c] * inv_count);
-    }
+    for (int e = 0; e < 8; ++e) o[e] = kg[e] * gv[e] + kx[e] * xv[e] + k0[e];
     ffa_store8<T>(dx + i * 8, o);
   }
 }
@@ -350,20 +384,23 @@ extern "C" int ffa_bn_bwd(int dtype, const void* x, const void* dy, const void* 
   float* ws = static_cast<float*>(workspace);
   const long long nvec = npix * (C / 8);
   const float inv_count = (float)(1.0 / (double)npix);
+  float* coef = ws + (long long)FFA_MAX_PARTIALS * 2 * C;
   if (dtype == FFA_BF16) {
     hipLaunchKernelGGL((channel_reduce_kernel<ffa_bf16, BnBwdOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
                        (const ffa_bf16*)x, (const ffa_bf16*)dy, (const ffa_bf16*)y, mean, rstd, ws, npix, C, relu);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ffa_cdiv(C, 128)), dim3(128), 0, stream, ws, nb, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ffa_cdiv(C, 8)), dim3(FFA_FIN_THREADS), 0, stream, ws, nb, C, gamma,
+                       mean, rstd, inv_count, dgamma, dbeta, coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<ffa_bf16>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
-                       (const ffa_bf16*)x, (const ffa_bf16*)dy, (const ffa_bf16*)y, gamma, mean, rstd, dgamma, dbeta,
-                       (ffa_bf16*)dx, (ffa_bf16*)dres, nvec, C, relu, inv_count);
+                       (const ffa_bf16*)x, (const ffa_bf16*)dy, (const ffa_bf16*)y, coef, (ffa_bf16*)dx,
+                       (ffa_bf16*)dres, nvec, C, relu);
   } else {
     hipLaunchKernelGGL((channel_reduce_kernel<float, BnBwdOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
                        (const float*)x, (const float*)dy, (const float*)y, mean, rstd, ws, npix, C, relu);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ffa_cdiv(C, 128)), dim3(128), 0, stream, ws, nb, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ffa_cdiv(C, 8)), dim3(FFA_FIN_THREADS), 0, stream, ws, nb, C, gamma,
+                       mean, rstd, inv_count, dgamma, dbeta, coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
-                       (const float*)x, (const float*)dy, (const float*)y, gamma, mean, rstd, dgamma, dbeta,
-                       (float*)dx, (float*)dres, nvec, C, relu, inv_count);
+                       (const float*)x, (const float*)dy, (const float*)y, coef, (float*)dx, (float*)dres, nvec, C,
+                       relu);
   }
   return ffa_check_launch("bn_bwd");
 }
@@ -513,8 +550,9 @@ extern "C" int ffa_channel_sums(int dtype, const void* x, long long npix, int C,
   else
     hipLaunchKernelGGL((channel_reduce_kernel<float, StatOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
                        (const float*)x, (const float*)nullptr, (const float*)nullptr, nullptr, nullptr, ws, npix, C, 0);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ffa_cdiv(C, 128)), dim3(128), 0, stream, ws, nb, C, sumsq_out,
-                     sum_out);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ffa_cdiv(C, 8)), dim3(FFA_FIN_THREADS), 0, stream, ws, nb, C,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, sumsq_out, sum_out,
+                     (float*)nullptr);
   return ffa_check_launch("channel_sums");
 }
 
