@@ -119,12 +119,10 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
   int aoff[G::MT];
 #pragma unroll
   for (int mt = 0; mt < G::MT; ++mt) {
-    int row;
-    if (G::MT == 2)
-      row = 16 * (rho >> 3) + 8 * ((rho >> 2) & 1) + 4 * mt + (rho & 3);
-    else
-      row = rho;
-    aoff[mt] = (wco * G::WAVE_CO + row) * G::WP + half * 16;
+    // LDS rows are stored in fragment order (row mt*32 + rho of a 64-row group holds output channel
+    // 16*(rho>>3) + 8*((rho>>2)&1) + 4*mt + (rho&3), the permutation is applied by ffa_pack_conv_weight), so
+    // neighbouring lanes read neighbouring rows: 19 slots per row is odd -> conflict-free ds_read_b128
+    aoff[mt] = (wco * G::WAVE_CO + mt * 32 + rho) * G::WP + half * 16;
   }
   int boff[G::NT];
 #pragma unroll
@@ -207,22 +205,40 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
     const bool more = (c + 1 < total_chunks);
     if (more) FFA_LOAD_CHUNK(c + 1)  // global loads stay in flight under the MFMAs below
 
+    // fragments are double-buffered in registers: the ds_reads of tap t+1 are issued before the MFMAs of
+    // tap t, so their LDS latency hides under the matrix pipe instead of stalling every tap
+    ffa_u32x4 af[2][G::MT], bf[2][G::NT];
 #pragma unroll
-    for (int r = 0; r < RG; ++r) {
+    for (int mt = 0; mt < G::MT; ++mt) af[0][mt] = *reinterpret_cast<const ffa_u32x4*>(sW + aoff[mt]);
 #pragma unroll
-      for (int s = 0; s < KW; ++s) {
-        const int tap = r * KW + s;
-        ffa_u32x4 af[G::MT], bf[G::NT];
+    for (int nt = 0; nt < G::NT; ++nt) bf[0][nt] = *reinterpret_cast<const ffa_u32x4*>(sIn + boff[nt]);
+#pragma unroll
+    for (int tap = 0; tap < G::TAPS; ++tap) {
+      const int cur = tap & 1, nxt = cur ^ 1;
+      if (tap + 1 < G::TAPS) {
+        const int r1 = (tap + 1) / KW, s1 = (tap + 1) % KW;
 #pragma unroll
         for (int mt = 0; mt < G::MT; ++mt)
-          af[mt] = *reinterpret_cast<const ffa_u32x4*>(sW + aoff[mt] + tap * 32);
+          af[nxt][mt] = *reinterpret_cast<const ffa_u32x4*>(sW + aoff[mt] + (tap + 1) * 32);
 #pragma unroll
         for (int nt = 0; nt < G::NT; ++nt)
-          bf[nt] = *reinterpret_cast<const ffa_u32x4*>(sIn + boff[nt] + (r * G::IW + s) * G::PP);
+          bf[nxt][nt] = *reinterpret_cast<const ffa_u32x4*>(sIn + boff[nt] + (r1 * G::IW + s1) * G::PP);
+      }
 #pragma unroll
-        for (int mt = 0; mt < G::MT; ++mt)
+      for (int mt = 0; mt < G::MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < G::NT; ++nt) Mma<T>::run(af[mt], bf[nt], acc[mt][nt]);
+        for (int nt = 0; nt < G::NT; ++nt) Mma<T>::run(af[cur][mt], bf[cur][nt], acc[mt][nt]);
+      // pin the interleave (hipcc otherwise sinks the reads back to just before their first use):
+      // one MFMA group, one ds_read, ... so every read has a full tap of matrix work to land under
+      if (tap + 1 < G::TAPS) {
+        constexpr int NR = G::MT + G::NT, NM = G::MT * G::NT;
+        constexpr int PER = (sizeof(T) == 2) ? 1 : 4;  // MFMAs per Mma<T>::run
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+          if (i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (NR > NM) __builtin_amdgcn_sched_group_barrier(0x100, NR - NM, 0);
       }
     }
     __syncthreads();
@@ -442,7 +458,12 @@ __global__ void pack_weight_kernel(PackArgs p) {
     const int rg = t % nrg; t /= nrg;
     const int cc = t % p.nchunks; t /= p.nchunks;
     const int cb = (int)t;
-    const int row = cb * p.bco + row_l;
+    int row_in_block = row_l;
+    if (p.bco >= 64) {  // fragment order inside each 64-row wave group (see conv_igemm_kernel)
+      const int j = row_l & 63, mt = j >> 5, rho = j & 31;
+      row_in_block = (row_l & ~63) + 16 * (rho >> 3) + 8 * ((rho >> 2) & 1) + 4 * mt + (rho & 3);
+    }
+    const int row = cb * p.bco + row_in_block;
     const int ch = cc * EPC + e;
     int r = rg * p.rg + tap / p.kw;
     int s = tap % p.kw;

@@ -183,21 +183,32 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
         const int pxl = px0 + 8 * khalf + (li >> 2);
         const unsigned char* bbase =
             inPlane + ((py * G::LS) * G::IW + pxl * G::LS) * G::ROWB + gsel * 32 + (li & 3) * 8;
+        // B fragments double-buffered: the two transpose reads of tap t+1 are issued before the MFMA of tap t
+        auto load_b = [&](int tap) {
+          const unsigned char* bp = bbase + ((tap / KW) * G::IW + (tap % KW)) * G::ROWB;
+          const ffa_s16x4 b0 = lds_read_tr16(bp);
+          const ffa_s16x4 b1 = lds_read_tr16(bp + 4 * G::LS * G::ROWB);
+          ffa_u32x4 bf;
+          bf.x = __builtin_bit_cast(ffa_u32x2, b0).x;
+          bf.y = __builtin_bit_cast(ffa_u32x2, b0).y;
+          bf.z = __builtin_bit_cast(ffa_u32x2, b1).x;
+          bf.w = __builtin_bit_cast(ffa_u32x2, b1).y;
+          return bf;
+        };
+        // prefetch distance 2: with one MFMA per tap a single tap (32 cycles) is shorter than the LDS latency
+        ffa_u32x4 bq[3];
+        bq[0] = load_b(0);
+        if (G::TAPS > 1) bq[1] = load_b(1);
 #pragma unroll
-        for (int r = 0; r < RG; ++r)
-#pragma unroll
-          for (int s = 0; s < KW; ++s) {
-            const unsigned char* bp = bbase + (r * G::IW + s) * G::ROWB;
-            const ffa_s16x4 b0 = lds_read_tr16(bp);
-            const ffa_s16x4 b1 = lds_read_tr16(bp + 4 * G::LS * G::ROWB);
-            ffa_u32x4 bf;
-            bf.x = __builtin_bit_cast(ffa_u32x2, b0).x;
-            bf.y = __builtin_bit_cast(ffa_u32x2, b0).y;
-            bf.z = __builtin_bit_cast(ffa_u32x2, b1).x;
-            bf.w = __builtin_bit_cast(ffa_u32x2, b1).y;
-            acc[r * KW + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(ffa_bf16x8, af), __builtin_bit_cast(ffa_bf16x8, bf), acc[r * KW + s], 0, 0, 0);
+        for (int tap = 0; tap < G::TAPS; ++tap) {
+          if (tap + 2 < G::TAPS) bq[(tap + 2) % 3] = load_b(tap + 2);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(ffa_bf16x8, af), __builtin_bit_cast(ffa_bf16x8, bq[tap % 3]), acc[tap], 0, 0, 0);
+          if (tap + 2 < G::TAPS) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           }
+        }
       } else {
         // f32: 8 MFMAs of k = 2 pixels; lane supplies A[co = lane&31][k = lane>>5], B[k][ci = lane&31]
 #pragma unroll

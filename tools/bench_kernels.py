@@ -1,0 +1,100 @@
+#!/usr/bin/env python
+"""Micro-benchmark of single libflairhip kernels on the layer shapes of the batch-32 U-Net step.
+
+  python tools/bench_kernels.py                 # table: shape, us, TFLOP/s or GB/s
+  python tools/bench_kernels.py --only conv128  # one shape, many launches (use under rocprofv3 --pmc)
+
+Inputs are random (never zeros: DVFS), each kernel is timed with HIP events on the stream it runs on,
+median of several batches of back-to-back launches.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flair-for-aigle_amd"))
+
+import torch
+
+from flairhip import ops
+
+B = 32
+# name, Cin, Cout, k, stride, pad, H (input), what
+CONV_SHAPES = [
+    ("conv64", 64, 64, 3, 1, 1, 128),
+    ("conv128", 128, 128, 3, 1, 1, 64),
+    ("conv256", 256, 256, 3, 1, 1, 32),
+    ("conv512", 512, 512, 3, 1, 1, 16),
+    ("dec0c1", 768, 256, 3, 1, 1, 32),
+    ("dec1c1", 384, 128, 3, 1, 1, 64),
+    ("dec2c1", 192, 64, 3, 1, 1, 128),
+    ("dec3c1", 128, 32, 3, 1, 1, 256),
+    ("dec3c2", 32, 32, 3, 1, 1, 256),
+    ("dec4c1", 32, 16, 3, 1, 1, 512),
+    ("dec4c2", 16, 16, 3, 1, 1, 512),
+    ("head", 16, 19, 3, 1, 1, 512),
+    ("l2down", 64, 128, 3, 2, 1, 128),
+    ("stem", 5, 64, 7, 2, 3, 512),
+]
+
+
+def timeit(fn, iters=20, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    best = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        best.append(s.elapsed_time(e) / iters * 1e3)
+    best.sort()
+    return best[len(best) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    dt = torch.bfloat16
+    kinds = args.kinds.split(",")
+    print(f"{'shape':10s} {'kind':6s} {'us':>9s} {'TFLOP/s':>9s} {'GB/s(min traffic)':>18s}")
+    for name, cin, cout, k, stride, pad, H in CONV_SHAPES:
+        if args.only and args.only != name:
+            continue
+        cip = ops.pad_channels(cin)
+        cop = 32 if cout == 19 else ops.pad_channels(cout)
+        Ho = (H + 2 * pad - k) // stride + 1
+        x = torch.randn(B, H, H, cip, device=dev).to(dt)
+        if cip > cin:
+            x[..., cin:] = 0
+        w = torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5
+        dy = torch.randn(B, Ho, Ho, cop, device=dev).to(dt)
+        flops = 2.0 * B * Ho * Ho * cout * cin * k * k
+        bytes_min = (x.numel() + dy.numel()) * 2
+        pw = ops.pack_conv_weight(w, dt, stride, cip)
+        pwt = ops.pack_conv_weight(w, dt, stride, cop, transpose=True)
+        out = torch.empty(B, Ho, Ho, cop, device=dev, dtype=dt)
+        dx = torch.empty(B, H, H, cip, device=dev, dtype=dt)
+        dw = torch.empty(cout, cin, k, k, device=dev)
+        runs = {
+            "fwd": lambda: ops.conv2d(x, pw, pad, cop, out=out),
+            "dgrad": lambda: ops.conv2d(dy, pwt, k - 1 - pad, cip, dil=stride, out_hw=(H, H), out=dx),
+            "wgrad": lambda: ops.conv_wgrad(x, dy, cout, cin, k, k, stride, pad, out=dw),
+        }
+        for kind in kinds:
+            if kind == "dgrad" and name == "stem":
+                continue
+            us = timeit(runs[kind], iters=args.iters)
+            print(f"{name:10s} {kind:6s} {us:9.1f} {flops / us / 1e6:9.1f} {bytes_min / us / 1e3:18.0f}")
+
+
+if __name__ == "__main__":
+    main()
