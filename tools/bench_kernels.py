@@ -80,7 +80,7 @@ def main():
         flops = 2.0 * B * Ho * Ho * cout * cin * k * k
         bytes_min = (x.numel() + dy.numel()) * 2
         pw = ops.pack_conv_weight(w, dt, stride, cip)
-        pwt = ops.pack_conv_weight(w, dt, stride, cop, transpose=True)
+        pwt = ops.pack_conv_weight(w, dt, stride, cop, transpose=True) if name != "stem" else None
         out = torch.empty(B, Ho, Ho, cop, device=dev, dtype=dt)
         dx = torch.empty(B, H, H, cip, device=dev, dtype=dt)
         dw = torch.empty(cout, cin, k, k, device=dev)
