@@ -15,6 +15,8 @@
 // slabs in fixed order (deterministic, no float atomics) and writes the OIHW f32 gradient.
 #include "ffa_common.h"
 
+#include <stdlib.h>
+
 struct WgradArgs {
   const void* x;
   const void* dy;
@@ -247,6 +249,221 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ring variant for the bulk of the network (bf16, 3x3 stride 1, >= 64 channels on both sides): one block per CU,
+// one wave per SIMD, up to 512 VGPRs per lane.  The spatial tiles of a split stream through a 3-slot LDS ring
+// filled by global_load_lds (LDS-DMA, no staging registers): while tile t is multiplied, tiles t+1 and t+2
+// are in flight, tracked with counted vmcnt and ONE raw s_barrier per tile.  A whole k-step's fragments (A + 9
+// taps of B) are double-buffered in registers so the transpose reads of step s+1 hide under the MFMAs of step s.
+// Out-of-image halo pixels and pad channels: the DMA is issued for every lane (wave-uniform instruction count
+// keeps vmcnt exact) from a safe address and the affected 16-byte pieces are overwritten with zeros after the
+// wait, before the barrier that publishes the tile.
+
+template <int TH, int TW>
+__global__ void __launch_bounds__(256, 1) conv_wgrad_ring_kernel(WgradArgs a) {
+  using G = WgradGeom<3, 3, 1, 3, 2, 2, 1, TH, TW, 2>;
+  constexpr int NSTAGE = 3;
+  constexpr int PIECES = G::DY_PIECES + G::IN_PIECES;
+  constexpr int NP = (PIECES + 255) / 256;  // LDS-DMA instructions per wave per tile
+  constexpr int STAGE_BYTES = NP * 256 * 16;
+  static_assert(G::DY_PIECES % 256 == 0, "dy pieces must fill whole instructions");
+  static_assert(NSTAGE * STAGE_BYTES <= 160 * 1024, "LDS budget");
+  __shared__ __align__(16) unsigned char smem[NSTAGE * STAGE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wco = wave >> 1, wci = wave & 1;
+  int tb = blockIdx.x;
+  const int cib = tb % a.ncib;
+  const int cob = tb / a.ncib;
+  const int split = blockIdx.y;
+  const int co0 = cob * 64, ci0 = cib * 64;
+
+  ffa_f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const unsigned char* x_b = static_cast<const unsigned char*>(a.x);
+  const unsigned char* dy_b = static_cast<const unsigned char*>(a.dy);
+  const int li = lane & 15, gsel = (lane >> 4) & 1, khalf = lane >> 5;
+  const int ntiles = (a.npt - split + a.nsplit - 1) / a.nsplit;  // tiles split, split + nsplit, ...
+
+  unsigned okmask[NSTAGE];
+
+  // Per-thread piece geometry is tile independent: the byte offset of every piece relative to the tile
+  // origin and four "edge" bit sets (piece lies in the halo's first / last row / column) are computed once.
+  // The host only selects this kernel when the tiles divide the image and pad == 1, so a piece can be outside
+  // the image only through those edges: per tile the invalid set is a handful of scalar selects, and every
+  // DMA address is (uniform 32-bit tile offset + per-lane constant) -- no per-piece bounds arithmetic.
+  int prel[NP];
+  unsigned pstatic_bad = 0, e_top = 0, e_bot = 0, e_left = 0, e_right = 0;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int i = tid + k * 256;
+    if (k * 256 < G::DY_PIECES) {
+      const int part = i % G::PARTS;
+      const int n = (i / G::PARTS) % G::NPX;
+      const int plane = i / (G::PARTS * G::NPX);
+      const int c = co0 + plane * 32 + part * 8;
+      prel[k] = (((n / TW) * a.Wo + (n % TW)) * a.Co + c) * 2;
+      pstatic_bad |= (c < a.Co ? 0u : 1u) << k;
+    } else {
+      const int jj = i - G::DY_PIECES;
+      const int part = jj % G::PARTS;
+      const int q = (jj / G::PARTS) % (G::IH * G::IW);
+      const int plane = jj / (G::PARTS * G::IH * G::IW);
+      const int c = ci0 + plane * 32 + part * 8;
+      const int r = q / G::IW, cc = q % G::IW;
+      prel[k] = ((r * a.Wi + cc) * a.Ci + c) * 2;
+      pstatic_bad |= ((jj < G::IN_PIECES && c < a.Ci) ? 0u : 1u) << k;
+      e_top |= (r == 0 ? 1u : 0u) << k;
+      e_bot |= (r == G::IH - 1 ? 1u : 0u) << k;
+      e_left |= (cc == 0 ? 1u : 0u) << k;
+      e_right |= (cc == G::IW - 1 ? 1u : 0u) << k;
+    }
+  }
+
+  int voff[NP];  // byte offsets (from dy / x base) of the tile being issued
+  auto prepare = [&](int t, int stage) {
+    const int pt = split + t * a.nsplit;
+    const int tx = pt % a.tiles_x;
+    const int t2 = pt / a.tiles_x;
+    const int ty = t2 % a.tiles_y;
+    const int b = t2 / a.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int dy_org = (((b * a.Ho + oy0) * a.Wo + ox0) * a.Co) * 2;
+    const int in_org = (((b * a.Hi + oy0 - 1) * a.Wi + ox0 - 1) * a.Ci) * 2;
+    unsigned bad = pstatic_bad;
+    if (oy0 == 0) bad |= e_top;
+    if (oy0 + TH == a.Ho) bad |= e_bot;
+    if (ox0 == 0) bad |= e_left;
+    if (ox0 + TW == a.Wo) bad |= e_right;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int off = (k * 256 < G::DY_PIECES ? dy_org : in_org) + prel[k];
+      voff[k] = ((bad >> k) & 1u) ? 0 : off;
+    }
+    okmask[stage] = bad;
+  };
+  auto emit = [&](int k, int stage) {
+    const unsigned char* base = (k * 256 < G::DY_PIECES) ? dy_b : x_b;
+    const unsigned lbase =
+        (unsigned)__builtin_amdgcn_readfirstlane((int)(stage * STAGE_BYTES + (wave * 64 + k * 256) * 16));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (unsigned)voff[k]),
+                                     (__attribute__((address_space(3))) void*)(smem + lbase), 16, 0, 0);
+  };
+  auto issue_all = [&](int t, int stage) {
+    prepare(t, stage);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) emit(k, stage);
+  };
+
+  if (ntiles > 0) issue_all(0, 0);
+  if (ntiles > 1) issue_all(1, 1);
+
+#pragma unroll 1
+  for (int t = 0; t < ntiles; ++t) {
+    const int stage = t % NSTAGE;
+    // this wave's DMA of tile t has landed when only the newer tile's NP instructions remain outstanding
+    if (t + 1 < ntiles) {
+      if (NP == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+      else if (NP == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    {
+      unsigned mask = stage == 0 ? okmask[0] : (stage == 1 ? okmask[1] : okmask[2]);
+      if (mask) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+          if (mask & (1u << k))
+            *reinterpret_cast<ffa_u32x4*>(smem + stage * STAGE_BYTES + (size_t)(tid + k * 256) * 16) =
+                ffa_u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool more = (t + 2 < ntiles);
+    const int nstage = (t + 2) % NSTAGE;
+    if (more) prepare(t + 2, nstage);  // the DMA instructions themselves are spread over the k-steps below
+
+    const unsigned char* sDy = smem + stage * STAGE_BYTES;
+    const unsigned char* sIn = sDy + G::DY_BYTES;
+    const unsigned char* dyPlane = sDy + wco * (G::NPX * G::ROWB) + gsel * 32 + (li & 3) * 8;
+    const unsigned char* inPlane = sIn + wci * (G::IH * G::IW * G::ROWB) + gsel * 32 + (li & 3) * 8;
+    const int lrow = 8 * khalf + (li >> 2);  // pixel of the k-step this lane addresses
+
+    ffa_u32x4 fa[2];
+    ffa_u32x4 fb[2][9];
+    auto tr2 = [&](const unsigned char* p0) {
+      const ffa_s16x4 v0 = lds_read_tr16(p0);
+      const ffa_s16x4 v1 = lds_read_tr16(p0 + 4 * G::ROWB);
+      ffa_u32x4 f;
+      f.x = __builtin_bit_cast(ffa_u32x2, v0).x;
+      f.y = __builtin_bit_cast(ffa_u32x2, v0).y;
+      f.z = __builtin_bit_cast(ffa_u32x2, v1).x;
+      f.w = __builtin_bit_cast(ffa_u32x2, v1).y;
+      return f;
+    };
+#define FFA_RING_LOAD(ks_, buf_)                                                                         \
+  {                                                                                                      \
+    constexpr int n0_ = (ks_) * 16;                                                                      \
+    constexpr int py_ = n0_ / TW, px0_ = n0_ % TW;                                                       \
+    fa[buf_] = tr2(dyPlane + (n0_ + lrow) * G::ROWB);                                                    \
+    const unsigned char* bb_ = inPlane + (py_ * G::IW + px0_ + lrow) * G::ROWB;                          \
+    _Pragma("unroll") for (int tap = 0; tap < 9; ++tap)                                                  \
+        fb[buf_][tap] = tr2(bb_ + ((tap / 3) * G::IW + (tap % 3)) * G::ROWB);                            \
+  }
+#define FFA_RING_MMA(buf_)                                                                                     \
+  _Pragma("unroll") for (int tap = 0; tap < 9; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(      \
+      __builtin_bit_cast(ffa_bf16x8, fa[buf_]), __builtin_bit_cast(ffa_bf16x8, fb[buf_][tap]), acc[tap], 0, 0, 0);
+#define FFA_RING_STEP(ks_)                                                              \
+  {                                                                                     \
+    __builtin_amdgcn_sched_barrier(0); /* keep each step's reads inside its own region */ \
+    if ((ks_) + 1 < G::KSTEPS) FFA_RING_LOAD(((ks_) + 1 < G::KSTEPS ? (ks_) + 1 : 0), ((ks_) + 1) & 1) \
+    FFA_RING_MMA((ks_) & 1)                                                             \
+    if (more) {                                                                         \
+      _Pragma("unroll") for (int k_ = (ks_); k_ < NP; k_ += G::KSTEPS) emit(k_, nstage); \
+    }                                                                                   \
+    if ((ks_) + 1 < G::KSTEPS) {                                                        \
+      _Pragma("unroll") for (int q_ = 0; q_ < 9; ++q_) {                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                              \
+      }                                                                                 \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                \
+    }                                                                                   \
+  }
+    FFA_RING_LOAD(0, 0)
+    FFA_RING_STEP(0)
+    FFA_RING_STEP(1)
+    FFA_RING_STEP(2)
+    FFA_RING_STEP(3)
+    FFA_RING_STEP(4)
+    FFA_RING_STEP(5)
+    FFA_RING_STEP(6)
+    FFA_RING_STEP(7)
+    static_assert(G::KSTEPS == 8, "ring kernel is written for 128-pixel tiles");
+#undef FFA_RING_LOAD
+#undef FFA_RING_MMA
+#undef FFA_RING_STEP
+  }
+
+  const int ci = ci0 + wci * 32 + (lane & 31);
+  const int co_w = co0 + wco * 32;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co_w + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      a.slabs[(((size_t)split * a.CoT + co) * 9 + t) * a.CiT + ci] = acc[t][r];
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int nsplit, int CoT, int CiT, int Co,
                     int Ci, int taps, int accumulate) {
@@ -284,7 +501,7 @@ wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int
 // ------------------------------------------------------------------------------------------------
 
 struct WgradPlan {
-  int wco, wci, wk, th, tw, rg, nsplit, ncob, ncib, CoT, CiT, npt, tiles_x, tiles_y;
+  int wco, wci, wk, th, tw, rg, nsplit, ncob, ncib, CoT, CiT, npt, tiles_x, tiles_y, ring;
 };
 
 static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, int B, int Ho, int Wo, WgradPlan* p) {
@@ -317,7 +534,17 @@ static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, in
   p->tiles_y = ffa_cdiv(Ho, p->th);
   p->npt = B * p->tiles_x * p->tiles_y;
   const int tile_blocks = p->ncob * p->ncib * (kh / p->rg);
-  int ns = ffa_cdiv(512, tile_blocks);  // ~2 blocks per CU; every split costs one f32 slab of HBM traffic
+  // conv_wgrad_ring_kernel (one block per CU, LDS-DMA ring): tiles must divide the image and offsets must fit
+  // 31 bits.  Measured on MI355X (tools/bench_kernels.py, round 1): 0.48-0.52 PFLOP/s vs 0.52-0.58 for the
+  // register-staged kernel at two blocks per CU -- SQ_WAIT_ANY 40 % of wave cycles, i.e. the DMA of 45 KB per
+  // 128-pixel tile does not arrive within two tiles of matrix work.  Kept selectable (FFA_WGRAD_RING=1) for the
+  // next round's work on the fill path (full-line piece order, deeper ring); off by default.
+  static const bool ring_enabled = getenv("FFA_WGRAD_RING") && getenv("FFA_WGRAD_RING")[0] == '1';
+  p->ring = (ring_enabled && s1 && !f32 && p->wco == 2 && p->wci == 2 && Ho % p->th == 0 && Wo % p->tw == 0 &&
+             (long long)B * Ho * Wo * (Co > Ci ? Co : Ci) * 2 < (1LL << 31))
+                ? 1
+                : 0;
+  int ns = ffa_cdiv(p->ring ? 256 : 512, tile_blocks);  // every split costs one f32 slab of HBM traffic
   if (ns > p->npt) ns = p->npt;
   if (ns < 1) ns = 1;
   p->nsplit = ns;
@@ -342,6 +569,14 @@ template <typename T>
 static int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int kh, int kw, int stride, hipStream_t stream) {
   constexpr bool F32 = (sizeof(T) == 4);
   const bool wide = (p.tw == 32);
+  if constexpr (!F32) {
+    if (p.ring) {
+      dim3 grid(a.ncob * a.ncib, a.nsplit);
+      if (wide) hipLaunchKernelGGL((conv_wgrad_ring_kernel<4, 32>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((conv_wgrad_ring_kernel<8, 16>), grid, dim3(256), 0, stream, a);
+      return ffa_check_launch("conv_wgrad_ring");
+    }
+  }
   if (kh == 3 && stride == 1) {
 #define FFA_WG_S1(WCO_, WCI_, WK_)                                                        \
   if (p.wco == WCO_ && p.wci == WCI_ && p.wk == WK_) {                                    \
@@ -390,6 +625,7 @@ extern "C" int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* d
     ffa_set_error("conv_wgrad: unsupported kernel %dx%d stride %d", kh, kw, stride);
     return FFA_ERR_UNSUPPORTED;
   }
+  if (pad != 1) p.ring = 0;  // the ring kernel's edge masks assume a one-pixel halo
   const long long need = (long long)p.nsplit * p.wk * p.CoT * kh * kw * p.CiT * (long long)sizeof(float);
   if (workspace_bytes < need) {
     ffa_set_error("conv_wgrad: workspace too small (%lld < %lld)", workspace_bytes, need);
