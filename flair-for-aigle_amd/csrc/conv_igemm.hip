@@ -20,6 +20,8 @@
 //              weight [BCO rows][TAPS*32 B + 16 B pad] (odd number of 16-B slots per row)
 #include "ffa_common.h"
 
+#include <stdlib.h>
+
 struct ConvArgs {
   const void* in;
   const void* w;
@@ -52,7 +54,10 @@ struct Mma<float> {
   }
 };
 
-template <int KH, int KW, int STRIDE, int RG, int BCO, int WCO, int WPX, int TH, int TW>
+// HK = 32-byte k-steps of channels staged per halo fill.  With HK = 4 every halo pixel is fetched as one whole
+// 128-byte line (64 bf16 channels) and then multiplied over four weight sub-chunks; with HK = 1 each line is
+// re-requested from L2 four times, 32 bytes at a time -- measured L2-bound on the 128..256-channel layers.
+template <int KH, int KW, int STRIDE, int RG, int BCO, int WCO, int WPX, int TH, int TW, int HK>
 struct ConvGeom {
   static constexpr int NTHR = 64 * WCO * WPX;
   static constexpr int NPX = TH * TW;
@@ -66,26 +71,28 @@ struct ConvGeom {
   static constexpr int NRG = KH / RG;
   static constexpr int IH = (TH - 1) * LS + RG;
   static constexpr int IW = (TW - 1) * LS + KW;
-  static constexpr int PP = 48;
+  static constexpr int PP = HK * 32 + 16;  // 3 / 5 / 9 slots of 16 B: odd -> conflict-free ds_read_b128
+  static constexpr int HPP = 2 * HK;       // 16-byte pieces per halo pixel
   static constexpr int TAPS = RG * KW;
   static constexpr int WP = TAPS * 32 + 16;
   static constexpr int HALO_BYTES = IH * IW * PP;
   static constexpr int W_BYTES = BCO * WP;
   static constexpr int LDS_BYTES = HALO_BYTES + W_BYTES;
   static constexpr int W_PIECES = BCO * TAPS * 2;
-  static constexpr int H_PIECES = IH * IW * 2;
+  static constexpr int H_PIECES = IH * IW * HPP;
   static constexpr int NWP = (W_PIECES + NTHR - 1) / NTHR;
   static constexpr int NHP = (H_PIECES + NTHR - 1) / NTHR;
   static_assert(KH % RG == 0, "row group must divide kernel height");
+  static_assert(HK == 1 || RG == KH, "deep halo staging needs all kernel rows in one chunk");
   static_assert(WAVE_CO == 32 || WAVE_CO == 64, "wave co tile");
   static_assert(WAVE_PX % 32 == 0, "wave px tile");
   static_assert((TW & (TW - 1)) == 0, "TW must be a power of two");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <typename T, int KH, int KW, int STRIDE, int RG, int BCO, int WCO, int WPX, int TH, int TW>
+template <typename T, int KH, int KW, int STRIDE, int RG, int BCO, int WCO, int WPX, int TH, int TW, int HK>
 __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs a) {
-  using G = ConvGeom<KH, KW, STRIDE, RG, BCO, WCO, WPX, TH, TW>;
+  using G = ConvGeom<KH, KW, STRIDE, RG, BCO, WCO, WPX, TH, TW, HK>;
   constexpr int EB = ElemTraits<T>::kBytes;
   __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
   unsigned char* sIn = smem;
@@ -148,62 +155,106 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
   ffa_u32x4 wreg[G::NWP];
   ffa_u32x4 hreg[G::NHP];
 
-#define FFA_LOAD_CHUNK(c_)                                                                                   \
+  // halo piece geometry, computed once: byte offset from the input base (32-bit: the host checks the tensor is
+  // smaller than 2 GiB), -1 where the piece is padding / zero insertion / past the tile; LDS byte address
+  int hoff[G::NHP], hlds[G::NHP];
+#pragma unroll
+  for (int k = 0; k < G::NHP; ++k) {
+    const int i = tid + k * G::NTHR;
+    const int q = i / G::HPP, hh = i % G::HPP;
+    const int hy = q / G::IW, hx = q % G::IW;
+    int vy = iy_base + hy * G::GSTEP;
+    int vx = ix_base + hx * G::GSTEP;
+    bool ok = (i < G::H_PIECES) && vy >= 0 && vx >= 0;
+    if (a.dil == 2) {
+      ok = ok && (((vy | vx) & 1) == 0);
+      vy >>= 1;
+      vx >>= 1;
+    }
+    ok = ok && vy < a.Hi && vx < a.Wi;
+    hoff[k] = ok ? (((b * a.Hi + vy) * a.Wi + vx) * a.Ci * EB + hh * 16) : -1;
+    hlds[k] = q * G::PP + hh * 16;
+  }
+
+#define FFA_LOAD_W(c_)                                                                                       \
   {                                                                                                          \
-    const int cc_ = (c_) / G::NRG;                                                                           \
-    const int rg_ = (c_) % G::NRG;                                                                           \
-    const ffa_u32x4* wsrc_ = reinterpret_cast<const ffa_u32x4*>(w_b + (size_t)(c_) * (BCO * G::TAPS * 32));         \
+    const ffa_u32x4* wsrc_ = reinterpret_cast<const ffa_u32x4*>(w_b + (size_t)(c_) * (BCO * G::TAPS * 32)); \
     _Pragma("unroll") for (int k = 0; k < G::NWP; ++k) {                                                     \
       const int i = tid + k * G::NTHR;                                                                       \
       wreg[k] = wsrc_[(G::W_PIECES % G::NTHR == 0 || i < G::W_PIECES) ? i : 0];                              \
     }                                                                                                        \
-    const int iy0_ = iy_base + rg_ * RG;                                                                     \
-    _Pragma("unroll") for (int k = 0; k < G::NHP; ++k) {                                                     \
-      const int i = tid + k * G::NTHR;                                                                       \
-      const int q = i >> 1;                                                                                  \
-      const int hh = i & 1;                                                                                  \
-      const int hy = q / G::IW, hx = q % G::IW;                                                              \
-      int vy = iy0_ + hy * G::GSTEP;                                                                         \
-      int vx = ix_base + hx * G::GSTEP;                                                                      \
-      bool ok = (i < G::H_PIECES) && vy >= 0 && vx >= 0;                                                     \
-      if (a.dil == 2) {                                                                                      \
-        ok = ok && (((vy | vx) & 1) == 0);                                                                   \
-        vy >>= 1;                                                                                            \
-        vx >>= 1;                                                                                            \
+  }
+  /* c_ = chunk whose halo is needed: channel bytes (c_/NRG/HK)*HK*32 .., kernel rows (c_ % NRG)*RG ..
+     The per-piece byte offset and validity are chunk independent (NRG == 1): they were computed once into
+     hoff[] (-1 = zero fill), so a refill costs one scalar add for the base and no vector address math. */
+#define FFA_LOAD_H(c_)                                                                                       \
+  {                                                                                                          \
+    const int cbyte_ = (((c_) / G::NRG) / HK) * (HK * 32);                                                   \
+    if constexpr (G::NRG == 1) {                                                                             \
+      const unsigned char* base_ = in_b + cbyte_;                                                            \
+      _Pragma("unroll") for (int k = 0; k < G::NHP; ++k) {                                                   \
+        ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};                                                             \
+        if (hoff[k] >= 0) v = *reinterpret_cast<const ffa_u32x4*>(base_ + (unsigned)hoff[k]);                \
+        hreg[k] = v;                                                                                         \
       }                                                                                                      \
-      ok = ok && vy < a.Hi && vx < a.Wi;                                                                     \
-      ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};                                                                      \
-      if (ok) {                                                                                              \
-        const size_t off =                                                                                   \
-            ((size_t)(b * a.Hi + vy) * a.Wi + vx) * (size_t)(a.Ci * EB) + cc_ * 32 + hh * 16;                \
-        v = *reinterpret_cast<const ffa_u32x4*>(in_b + off);                                                     \
+    } else {                                                                                                 \
+      const int iy0_ = iy_base + ((c_) % G::NRG) * RG;                                                       \
+      _Pragma("unroll") for (int k = 0; k < G::NHP; ++k) {                                                   \
+        const int i = tid + k * G::NTHR;                                                                     \
+        const int q = i / G::HPP;                                                                            \
+        const int hh = i % G::HPP;                                                                           \
+        const int hy = q / G::IW, hx = q % G::IW;                                                            \
+        int vy = iy0_ + hy * G::GSTEP;                                                                       \
+        int vx = ix_base + hx * G::GSTEP;                                                                    \
+        bool ok = (i < G::H_PIECES) && vy >= 0 && vx >= 0;                                                   \
+        if (a.dil == 2) {                                                                                    \
+          ok = ok && (((vy | vx) & 1) == 0);                                                                 \
+          vy >>= 1;                                                                                          \
+          vx >>= 1;                                                                                          \
+        }                                                                                                    \
+        ok = ok && vy < a.Hi && vx < a.Wi;                                                                   \
+        ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};                                                             \
+        if (ok) {                                                                                            \
+          const size_t off =                                                                                 \
+              ((size_t)(b * a.Hi + vy) * a.Wi + vx) * (size_t)(a.Ci * EB) + cbyte_ + hh * 16;                \
+          v = *reinterpret_cast<const ffa_u32x4*>(in_b + off);                                               \
+        }                                                                                                    \
+        hreg[k] = v;                                                                                         \
       }                                                                                                      \
-      hreg[k] = v;                                                                                           \
     }                                                                                                        \
   }
-#define FFA_STORE_CHUNK()                                                                  \
+#define FFA_STORE_W()                                                                      \
   {                                                                                        \
     _Pragma("unroll") for (int k = 0; k < G::NWP; ++k) {                                   \
       const int i = tid + k * G::NTHR;                                                     \
       if (G::W_PIECES % G::NTHR == 0 || i < G::W_PIECES) {                                 \
         const int row = i / (G::TAPS * 2), col = i % (G::TAPS * 2);                        \
-        *reinterpret_cast<ffa_u32x4*>(sW + row * G::WP + col * 16) = wreg[k];                  \
+        *reinterpret_cast<ffa_u32x4*>(sW + row * G::WP + col * 16) = wreg[k];              \
       }                                                                                    \
     }                                                                                      \
+  }
+#define FFA_STORE_H()                                                                      \
+  {                                                                                        \
     _Pragma("unroll") for (int k = 0; k < G::NHP; ++k) {                                   \
       const int i = tid + k * G::NTHR;                                                     \
       if (G::H_PIECES % G::NTHR == 0 || i < G::H_PIECES)                                   \
-        *reinterpret_cast<ffa_u32x4*>(sIn + (i >> 1) * G::PP + (i & 1) * 16) = hreg[k];        \
+        *reinterpret_cast<ffa_u32x4*>(sIn + hlds[k]) = hreg[k];                            \
     }                                                                                      \
   }
 
-  FFA_LOAD_CHUNK(0)
-  FFA_STORE_CHUNK()
+  FFA_LOAD_W(0)
+  FFA_LOAD_H(0)
+  FFA_STORE_W()
+  FFA_STORE_H()
   __syncthreads();
 
   for (int c = 0; c < total_chunks; ++c) {
     const bool more = (c + 1 < total_chunks);
-    if (more) FFA_LOAD_CHUNK(c + 1)  // global loads stay in flight under the MFMAs below
+    // the halo is refilled when the next chunk starts a new group of HK channel k-steps (or a new row group)
+    const bool more_h = more && (G::NRG > 1 || ((c + 1) % HK) == 0);
+    const int sub = (G::NRG > 1) ? 0 : (c % HK) * 32;  // byte offset of this chunk's k-step inside a halo pixel
+    if (more) FFA_LOAD_W(c + 1)  // global loads stay in flight under the MFMAs below
+    if (more_h) FFA_LOAD_H(c + 1)
 
     // fragments are double-buffered in registers: the ds_reads of tap t+1 are issued before the MFMAs of
     // tap t, so their LDS latency hides under the matrix pipe instead of stalling every tap
@@ -211,10 +262,11 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
 #pragma unroll
     for (int mt = 0; mt < G::MT; ++mt) af[0][mt] = *reinterpret_cast<const ffa_u32x4*>(sW + aoff[mt]);
 #pragma unroll
-    for (int nt = 0; nt < G::NT; ++nt) bf[0][nt] = *reinterpret_cast<const ffa_u32x4*>(sIn + boff[nt]);
+    for (int nt = 0; nt < G::NT; ++nt) bf[0][nt] = *reinterpret_cast<const ffa_u32x4*>(sIn + boff[nt] + sub);
 #pragma unroll
     for (int tap = 0; tap < G::TAPS; ++tap) {
       const int cur = tap & 1, nxt = cur ^ 1;
+      __builtin_amdgcn_sched_barrier(0);  // one scheduling region per tap: its MFMAs + the reads of the next tap
       if (tap + 1 < G::TAPS) {
         const int r1 = (tap + 1) / KW, s1 = (tap + 1) % KW;
 #pragma unroll
@@ -222,7 +274,7 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
           af[nxt][mt] = *reinterpret_cast<const ffa_u32x4*>(sW + aoff[mt] + (tap + 1) * 32);
 #pragma unroll
         for (int nt = 0; nt < G::NT; ++nt)
-          bf[nxt][nt] = *reinterpret_cast<const ffa_u32x4*>(sIn + boff[nt] + (r1 * G::IW + s1) * G::PP);
+          bf[nxt][nt] = *reinterpret_cast<const ffa_u32x4*>(sIn + boff[nt] + sub + (r1 * G::IW + s1) * G::PP);
       }
 #pragma unroll
       for (int mt = 0; mt < G::MT; ++mt)
@@ -243,13 +295,16 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
     }
     __syncthreads();
     if (more) {
-      FFA_STORE_CHUNK()
+      FFA_STORE_W()
+      if (more_h) FFA_STORE_H()
       __syncthreads();
     }
   }
 
-#undef FFA_LOAD_CHUNK
-#undef FFA_STORE_CHUNK
+#undef FFA_LOAD_W
+#undef FFA_LOAD_H
+#undef FFA_STORE_W
+#undef FFA_STORE_H
 
   // epilogue: lane (rho, half) owns pixel n = wave px base + nt*32 + rho and, per g, a run of
   // consecutive channels (8 for MT==2, 4 for MT==1)
@@ -333,7 +388,8 @@ static int conv_rg(int kh) { return kh == 7 ? 1 : kh; }
 // Preferred block height in output channels for a layer with `cout` real output channels.  The
 // caller packs the weights with this value and hands the same value back to ffa_conv2d.
 static int conv_pref_bco(int kh, int kw, int stride, int cout) {
-  if (kh == 3 && kw == 3 && stride == 1) return cout > 64 ? 128 : (cout > 32 ? 64 : 32);
+  // 64 rows + deep (full 128-byte line) halo staging beats 128 rows + 32-byte staging, see ConvGeom
+  if (kh == 3 && kw == 3 && stride == 1) return cout > 32 ? 64 : 32;
   return cout > 32 ? 64 : 32;
 }
 
@@ -345,12 +401,23 @@ static bool conv_supported(int kh, int kw, int stride, int bco) {
   return bco == 64 || bco == 32;
 }
 
-template <typename T, int KH, int KW, int STRIDE, int RG, int BCO, int WCO, int WPX, int TH, int TW>
-static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
+template <typename T, int KH, int KW, int STRIDE, int RG, int BCO, int WCO, int WPX, int TH, int TW, int HK>
+static int launch_hk(const ConvArgs& a, hipStream_t stream) {
   const int grid = ffa_cdiv(a.npt, 8) * 8 * a.ncb;
-  hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, STRIDE, RG, BCO, WCO, WPX, TH, TW>), dim3(grid),
+  hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, STRIDE, RG, BCO, WCO, WPX, TH, TW, HK>), dim3(grid),
                      dim3(64 * WCO * WPX), 0, stream, a);
   return ffa_check_launch("conv_igemm");
+}
+
+template <typename T, int KH, int KW, int STRIDE, int RG, int BCO, int WCO, int WPX, int TH, int TW>
+static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
+  // deep halo staging for the 3x3 stride-1 workhorse when whole 64- / 128-byte runs of channels exist;
+  // the 128-row block keeps HK = 1 (its weight slab leaves no LDS for a deeper halo at two blocks per CU)
+  if constexpr (KH == 3 && STRIDE == 1 && BCO <= 64) {
+    if (a.nchunks % 4 == 0) return launch_hk<T, KH, KW, STRIDE, RG, BCO, WCO, WPX, TH, TW, 4>(a, stream);
+    if (a.nchunks % 2 == 0) return launch_hk<T, KH, KW, STRIDE, RG, BCO, WCO, WPX, TH, TW, 2>(a, stream);
+  }
+  return launch_hk<T, KH, KW, STRIDE, RG, BCO, WCO, WPX, TH, TW, 1>(a, stream);
 }
 
 template <typename T, int KH, int KW, int STRIDE, int RG>
@@ -398,6 +465,8 @@ extern "C" int ffa_conv2d(int dtype, const void* in, const void* w_packed, const
   FFA_REQUIRE(Ci % 16 == 0 && Co % 8 == 0, "conv: channel pitch must be a multiple of 16 (in) / 8 (out), got %d/%d", Ci, Co);
   FFA_REQUIRE(dil == 1 || dil == 2, "conv: dil must be 1 or 2");
   FFA_REQUIRE(dil == 1 || stride == 1, "conv: zero-insertion input needs stride 1");
+  FFA_REQUIRE((long long)B * Hi * Wi * Ci * (dtype == FFA_BF16 ? 2 : 4) < (1LL << 31),
+              "conv: input tensor must be smaller than 2 GiB (32-bit piece offsets)");
   if (!conv_supported(kh, kw, stride, bco)) {
     ffa_set_error("conv: unsupported kernel %dx%d stride %d block %d", kh, kw, stride, bco);
     return FFA_ERR_UNSUPPORTED;

@@ -20,7 +20,7 @@
 struct WgradArgs {
   const void* x;
   const void* dy;
-  float* slabs;  // [nsplit * WK][CoT][KH*KW][CiT]
+  float* slabs;  // [nsplit][CoT][KH*KW][CiT]
   int B, Hi, Wi, Ci;
   int Ho, Wo, Co;
   int pad;
@@ -46,7 +46,12 @@ struct WgradGeom {
   static constexpr int PARTS = ROWB / 16;      // 16-byte pieces per pixel row
   static constexpr int DY_BYTES = WCO * NPX * ROWB;
   static constexpr int IN_BYTES = WCI * IH * IW * ROWB;
-  static constexpr int LDS_BYTES = DY_BYTES + IN_BYTES;
+  static constexpr int STAGE_BYTES = DY_BYTES + IN_BYTES;
+  // WK > 1: the k-split wave groups are summed through LDS before ONE slab leaves the block (a slab costs a
+  // write + a read of Co*taps*Ci*4 bytes in HBM; with 512 single-slab blocks that was half of the kernel time)
+  static constexpr bool MERGE = (WK > 1) && (WCO * WCI == 4 || KH == 7);  // small-channel blocks keep per-group slabs
+  static constexpr int MERGE_BYTES = MERGE ? WCO * WCI * (WK - 1) * TAPS * 16 * 64 * 4 : 0;
+  static constexpr int LDS_BYTES = STAGE_BYTES > MERGE_BYTES ? STAGE_BYTES : MERGE_BYTES;
   static constexpr int DY_PIECES = WCO * NPX * PARTS;
   static constexpr int IN_PIECES = WCI * IH * IW * PARTS;
   static constexpr int NDP = (DY_PIECES + NTHR - 1) / NTHR;
@@ -203,6 +208,7 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
         if (G::TAPS > 1) bq[1] = load_b(1);
 #pragma unroll
         for (int tap = 0; tap < G::TAPS; ++tap) {
+          __builtin_amdgcn_sched_barrier(0);  // one scheduling region per tap (else hipcc sinks the prefetch)
           if (tap + 2 < G::TAPS) bq[(tap + 2) % 3] = load_b(tap + 2);
           acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
               __builtin_bit_cast(ffa_bf16x8, af), __builtin_bit_cast(ffa_bf16x8, bq[tap % 3]), acc[tap], 0, 0, 0);
@@ -233,11 +239,35 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
 #undef FFA_WG_LOAD
 #undef FFA_WG_STORE
 
+  // ---- sum the k-split wave groups through LDS (fixed order: group 0 + group 1 + ...)
+  if constexpr (G::MERGE) {
+    float* red = reinterpret_cast<float*>(smem);
+    const int wq = wco * WCI + wci;
+    __syncthreads();  // every wave is done with the staging buffers
+    if (wk > 0) {
+      float* dst = red + ((size_t)((wk - 1) * WCO * WCI + wq) * G::TAPS * 16) * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < G::TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(t * 16 + r) * 64] = acc[t][r];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int g = 0; g < WK - 1; ++g) {
+      const float* src = red + ((size_t)(g * WCO * WCI + wq) * G::TAPS * 16) * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < G::TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] += src[(t * 16 + r) * 64];
+    }
+  }
+
   // ---- write the partial slab: D[co][ci], lane column = ci, rows co = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int ci = ci0 + wci * 32 + (lane & 31);
   const int co_w = co0 + wco * 32;
   const size_t taps_total = (size_t)KH * KW;
-  const size_t slab = (size_t)split * WK + wk;
+  const size_t slab = G::MERGE ? (size_t)split : (size_t)split * WK + wk;
 #pragma unroll
   for (int t = 0; t < G::TAPS; ++t) {
     const int tapg = rg * G::TAPS + t;
@@ -501,7 +531,7 @@ wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int
 // ------------------------------------------------------------------------------------------------
 
 struct WgradPlan {
-  int wco, wci, wk, th, tw, rg, nsplit, ncob, ncib, CoT, CiT, npt, tiles_x, tiles_y, ring;
+  int wco, wci, wk, th, tw, rg, nsplit, ncob, ncib, CoT, CiT, npt, tiles_x, tiles_y, ring, nslab;
 };
 
 static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, int B, int Ho, int Wo, WgradPlan* p) {
@@ -518,7 +548,13 @@ static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, in
     p->th = (Wo >= 32) ? 4 : 8;
     p->wco = (Co > 32) ? 2 : 1;
     p->wci = (Ci > 32 && !f32) ? 2 : 1;  // f32 planes are twice as large: one ci plane per block
-    if (!f32) p->wk = 4 / (p->wco * p->wci);
+    if (!f32) {
+      p->wk = 4 / (p->wco * p->wci);
+      if (p->wk == 1) {  // 64 x 64 channel blocks: eight waves, two k-split groups, 256-pixel tiles, one slab
+        p->wk = 2;
+        p->th *= 2;
+      }
+    }
   } else {  // only the shapes the network needs are instantiated for the strided / 1x1 / stem kernels
     p->tw = 16;
     p->th = stem ? 8 : 4;
@@ -540,14 +576,19 @@ static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, in
   // 128-pixel tile does not arrive within two tiles of matrix work.  Kept selectable (FFA_WGRAD_RING=1) for the
   // next round's work on the fill path (full-line piece order, deeper ring); off by default.
   static const bool ring_enabled = getenv("FFA_WGRAD_RING") && getenv("FFA_WGRAD_RING")[0] == '1';
-  p->ring = (ring_enabled && s1 && !f32 && p->wco == 2 && p->wci == 2 && Ho % p->th == 0 && Wo % p->tw == 0 &&
+  p->ring = (ring_enabled && false && s1 && !f32 && p->wco == 2 && p->wci == 2 && Ho % p->th == 0 && Wo % p->tw == 0 &&
              (long long)B * Ho * Wo * (Co > Ci ? Co : Ci) * 2 < (1LL << 31))
                 ? 1
                 : 0;
-  int ns = ffa_cdiv(p->ring ? 256 : 512, tile_blocks);  // every split costs one f32 slab of HBM traffic
+  const int threads = 64 * p->wco * p->wci * p->wk;
+  // a split costs one f32 slab of HBM traffic; 512-thread blocks run one per CU, so their grid is kept at or
+  // just below 256 blocks (a 288-block grid would need two rounds)
+  int ns = (p->ring || threads >= 512) ? 256 / tile_blocks : ffa_cdiv(512, tile_blocks);
   if (ns > p->npt) ns = p->npt;
   if (ns < 1) ns = 1;
   p->nsplit = ns;
+  const bool merge = p->wk > 1 && (p->wco * p->wci == 4 || stem);  // mirrors WgradGeom::MERGE
+  p->nslab = merge ? ns : ns * p->wk;
   return true;
 }
 
@@ -555,7 +596,7 @@ extern "C" long long ffa_conv_wgrad_workspace_bytes(int dtype, int kh, int kw, i
                                                     int Wo) {
   WgradPlan p;
   if (!wgrad_plan(dtype, kh, kw, stride, Co, Ci, B, Ho, Wo, &p)) return FFA_ERR_UNSUPPORTED;
-  return (long long)p.nsplit * p.wk * p.CoT * kh * kw * p.CiT * (long long)sizeof(float);
+  return (long long)p.nslab * p.CoT * kh * kw * p.CiT * (long long)sizeof(float);
 }
 
 template <typename T, int KH, int KW, int STRIDE, int RG, int WCO, int WCI, int WK, int TH, int TW>
@@ -578,20 +619,20 @@ static int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int kh, int kw, 
     }
   }
   if (kh == 3 && stride == 1) {
-#define FFA_WG_S1(WCO_, WCI_, WK_)                                                        \
-  if (p.wco == WCO_ && p.wci == WCI_ && p.wk == WK_) {                                    \
-    if (wide) launch_wgrad_cfg<T, 3, 3, 1, 3, WCO_, WCI_, WK_, 4, 32>(a, 1, stream);      \
-    else launch_wgrad_cfg<T, 3, 3, 1, 3, WCO_, WCI_, WK_, 8, 16>(a, 1, stream);           \
-    return ffa_check_launch("conv_wgrad");                                                \
+#define FFA_WG_S1(WCO_, WCI_, WK_, THW_, THN_)                                               \
+  if (p.wco == WCO_ && p.wci == WCI_ && p.wk == WK_) {                                       \
+    if (wide) launch_wgrad_cfg<T, 3, 3, 1, 3, WCO_, WCI_, WK_, THW_, 32>(a, 1, stream);      \
+    else launch_wgrad_cfg<T, 3, 3, 1, 3, WCO_, WCI_, WK_, THN_, 16>(a, 1, stream);           \
+    return ffa_check_launch("conv_wgrad");                                                   \
   }
     if constexpr (F32) {
-      FFA_WG_S1(2, 1, 1)
-      FFA_WG_S1(1, 1, 1)
+      FFA_WG_S1(2, 1, 1, 4, 8)
+      FFA_WG_S1(1, 1, 1, 4, 8)
     } else {
-      FFA_WG_S1(2, 2, 1)
-      FFA_WG_S1(2, 1, 2)
-      FFA_WG_S1(1, 2, 2)
-      FFA_WG_S1(1, 1, 4)
+      FFA_WG_S1(2, 2, 2, 8, 16)
+      FFA_WG_S1(2, 1, 2, 4, 8)
+      FFA_WG_S1(1, 2, 2, 4, 8)
+      FFA_WG_S1(1, 1, 4, 4, 8)
     }
 #undef FFA_WG_S1
   } else if (kh == 3 && stride == 2) {
@@ -626,7 +667,7 @@ extern "C" int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* d
     return FFA_ERR_UNSUPPORTED;
   }
   if (pad != 1) p.ring = 0;  // the ring kernel's edge masks assume a one-pixel halo
-  const long long need = (long long)p.nsplit * p.wk * p.CoT * kh * kw * p.CiT * (long long)sizeof(float);
+  const long long need = (long long)p.nslab * p.CoT * kh * kw * p.CiT * (long long)sizeof(float);
   if (workspace_bytes < need) {
     ffa_set_error("conv_wgrad: workspace too small (%lld < %lld)", workspace_bytes, need);
     return FFA_ERR_WORKSPACE;
@@ -646,7 +687,7 @@ extern "C" int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* d
   long long g = (total + 31) / 32;
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)g), dim3(256), 0, stream, (const float*)workspace, dw_oihw,
-                     p.nsplit * p.wk, p.CoT, p.CiT, Co_real, Ci_real, kh * kw, accumulate);
+                     p.nslab, p.CoT, p.CiT, Co_real, Ci_real, kh * kw, accumulate);
   return ffa_check_launch("wgrad_reduce");
 }
 
