@@ -96,6 +96,34 @@ class KernelTimer:
         return {k: {"flops": v[0], "seconds": v[1], "launches": v[2]} for k, v in agg.items()}
 
 
+def pmc_traffic(symbol: str):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE are
+    collected in their own rocprofv3 runs, never together with timing): profiles/r01_pmc_traffic.json.
+    Returns None when no counter run matches the symbol."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    import re
+    m = re.match(r"(conv_igemm_kernel|conv_wgrad_kernel)<(bf16|f32),(\d)x\d,s(\d),(?:bco(\d+)|w(\d)x(\d)),?(\d+x\d+)?", symbol)
+    if not m:
+        return None
+    kind, dt, k, st = m.group(1), ("ffa_bf16" if m.group(2) == "bf16" else "float"), m.group(3), m.group(4)
+    best = None
+    for name, v in json.load(open(path))["kernels"].items():
+        if not name.startswith(f"void {kind}<{dt}, {k}, {k}, {st},"):
+            continue
+        if kind == "conv_igemm_kernel":
+            th, tw = (m.group(8) or "8x32").split("x")
+            if f", {m.group(5)}, " not in name or f", {th}, {tw}," not in name:
+                continue
+        else:
+            if f", {m.group(6)}, {m.group(7)}," not in name:
+                continue
+        if best is None or v["launches"] > best["launches"]:
+            best = v
+    return None if best is None else round(best["hbm_bytes_per_launch"])
+
+
 def cpu_baseline(budget_s: float = 25.0):
     """The oracle's training step on the host cores (fp32, NCHW, eager, AdamW): B=2 tiles per step."""
     import torch.nn.functional as F
@@ -227,7 +255,7 @@ def main():
         ach = dom[1]["flops"] / dom[1]["seconds"] / 1e12
         mfma_total = sum(v["seconds"] for v in summ.values())
         roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
+                    "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom[0]),
                     "launches_per_step": dom[1]["launches"] / args.steps,
                     "avg_launch_ms": round(dom[1]["seconds"] / dom[1]["launches"] * 1e3, 4),
                     "mfma_kernels_share_of_step": round(mfma_total / elapsed, 4)}
