@@ -90,10 +90,14 @@ extern "C" int ffa_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, i
 // per-channel two-value reductions over [N pixels][C]:  thread t owns channel group t % CG and
 // pixel lane t / CG; block partials land in ws[block][2][C]
 
+// relu modes of the backward kernels: 0 = none, 1 = mask from the stored forward output y (needed when a residual
+// was added before the ReLU), 2 = mask recomputed from x as (x*scale + shift > 0) with the same fma the forward
+// pass used -- saves reading y (one third of the reduce pass, one quarter of the apply pass)
 struct StatOp {  // sum(x), sum(x^2)
+  __device__ __forceinline__ void init(int, const float*, const float*, const float*, const float*) {}
   template <typename T>
   __device__ __forceinline__ void operator()(long long off, float (&a)[8], float (&b)[8], const T* x, const T*,
-                                             const T*, const float*, const float*, int, int) const {
+                                             const T*, int) const {
     float v[8];
     ffa_load8<T>(x + off, v);
 #pragma unroll
@@ -104,23 +108,36 @@ struct StatOp {  // sum(x), sum(x^2)
   }
 };
 
-struct BnBwdOp {  // sum(g), sum(g * xhat) with g = dy * (y > 0 if relu)
+struct BnBwdOp {  // sum(g), sum(g * xhat) with g = dy masked by the ReLU
+  float mean[8], rstd[8], sc[8], sh[8];
+  __device__ __forceinline__ void init(int c0, const float* m, const float* r, const float* gamma, const float* beta) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      mean[e] = m[c0 + e];
+      rstd[e] = r[c0 + e];
+      sc[e] = (gamma ? gamma[c0 + e] : 1.f) * rstd[e];
+      sh[e] = (beta ? beta[c0 + e] : 0.f) - mean[e] * sc[e];
+    }
+  }
   template <typename T>
   __device__ __forceinline__ void operator()(long long off, float (&a)[8], float (&b)[8], const T* x, const T* dy,
-                                             const T* y, const float* mean, const float* rstd, int c0, int relu) const {
+                                             const T* y, int relu) const {
     float xv[8], gv[8];
     ffa_load8<T>(x + off, xv);
     ffa_load8<T>(dy + off, gv);
-    if (relu) {
+    if (relu == 1) {
       float yv[8];
       ffa_load8<T>(y + off, yv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) gv[e] = yv[e] > 0.f ? gv[e] : 0.f;
+    } else if (relu == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gv[e] = (xv[e] * sc[e] + sh[e]) > 0.f ? gv[e] : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       a[e] += gv[e];
-      b[e] += gv[e] * (xv[e] - mean[c0 + e]) * rstd[c0 + e];
+      b[e] += gv[e] * (xv[e] - mean[e]) * rstd[e];
     }
   }
 };
@@ -128,7 +145,8 @@ struct BnBwdOp {  // sum(g), sum(g * xhat) with g = dy * (y > 0 if relu)
 template <typename T, typename Op>
 __global__ void __launch_bounds__(FFA_EW_THREADS)
 channel_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
-                      const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ ws,
+                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                      const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ ws,
                       long long npix, int C, int relu) {
   __shared__ float red[FFA_EW_THREADS][17];
   const int CG = C / 8;
@@ -140,8 +158,9 @@ channel_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T
   for (int e = 0; e < 8; ++e) a[e] = b[e] = 0.f;
   if (pl < PL) {
     Op op;
+    op.init(cg * 8, mean, rstd, gamma, beta);
     for (long long p = (long long)blockIdx.x * PL + pl; p < npix; p += (long long)gridDim.x * PL)
-      op(p * C + cg * 8, a, b, x, dy, y, mean, rstd, cg * 8, relu);
+      op(p * C + cg * 8, a, b, x, dy, y, relu);
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -168,7 +187,7 @@ static int reduce_blocks(long long npix, int C) {
 
 extern "C" long long ffa_bn_workspace_bytes(int C) {
   // block partials [FFA_MAX_PARTIALS][2][C] + three per-channel coefficient vectors for the backward apply
-  return ((long long)FFA_MAX_PARTIALS * 2 * C + 4LL * C) * (long long)sizeof(float);
+  return ((long long)FFA_MAX_PARTIALS * 2 * C + 6LL * C) * (long long)sizeof(float);
 }
 
 // Fixed-order sum of the block partials ws[p][which][C]: 256 threads = 32 partial lanes x 8 channels; lane l
@@ -243,11 +262,12 @@ extern "C" int ffa_bn_stats(int dtype, const void* x, long long npix, int C, con
   float* ws = static_cast<float*>(workspace);
   if (dtype == FFA_BF16)
     hipLaunchKernelGGL((channel_reduce_kernel<ffa_bf16, StatOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
-                       (const ffa_bf16*)x, (const ffa_bf16*)nullptr, (const ffa_bf16*)nullptr, nullptr, nullptr, ws,
+                       (const ffa_bf16*)x, (const ffa_bf16*)nullptr, (const ffa_bf16*)nullptr, nullptr, nullptr, nullptr, nullptr, ws,
                        npix, C, 0);
   else
     hipLaunchKernelGGL((channel_reduce_kernel<float, StatOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
-                       (const float*)x, (const float*)nullptr, (const float*)nullptr, nullptr, nullptr, ws, npix, C, 0);
+                       (const float*)x, (const float*)nullptr, (const float*)nullptr, nullptr, nullptr, nullptr, nullptr, ws, npix,
+                       C, 0);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ffa_cdiv(C, 8)), dim3(FFA_FIN_THREADS), 0, stream, ws, nb, (double)npix,
                      C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, rstd_out);
   return ffa_check_launch("bn_stats");
@@ -322,7 +342,7 @@ extern "C" int ffa_bn_apply(int dtype, const void* x, const void* residual, void
 //   kg = gamma*rstd, kx = -kg*rstd*dgamma/N, k0 = -kg*dbeta/N - kx*mean
 __global__ void __launch_bounds__(FFA_FIN_THREADS)
 bn_bwd_finalize_kernel(const float* __restrict__ ws, int nparts, int C, const float* __restrict__ gamma,
-                       const float* __restrict__ mean, const float* __restrict__ rstd, float inv_count,
+                       const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd, float inv_count,
                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
   int c;
   double s, q;
@@ -335,6 +355,8 @@ bn_bwd_finalize_kernel(const float* __restrict__ ws, int nparts, int C, const fl
     coef[c] = kg;
     coef[C + c] = kx;
     coef[2 * C + c] = -kg * (float)s * inv_count - kx * mean[c];
+    coef[3 * C + c] = kg;  // forward scale = gamma * rstd
+    coef[4 * C + c] = (beta ? beta[c] : 0.f) - mean[c] * kg;  // forward shift, same expression as bn_finalize
   }
 }
 
@@ -352,11 +374,17 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
     ffa_load8<float>(coef + c0, kg);
     ffa_load8<float>(coef + C + c0, kx);
     ffa_load8<float>(coef + 2 * C + c0, k0);
-    if (relu) {
+    if (relu == 1) {
       float yv[8];
       ffa_load8<T>(y + i * 8, yv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) gv[e] = yv[e] > 0.f ? gv[e] : 0.f;
+    } else if (relu == 2) {
+      float sc[8], sh[8];
+      ffa_load8<float>(coef + 3 * C + c0, sc);
+      ffa_load8<float>(coef + 4 * C + c0, sh);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gv[e] = (xv[e] * sc[e] + sh[e]) > 0.f ? gv[e] : 0.f;
     }
     if (dres) ffa_store8<T>(dres + i * 8, gv);
     float o[8];
@@ -370,11 +398,13 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
 // when relu), saved mean/rstd.  Outputs: dx, dgamma, dbeta and -- when dres is non-null -- the gradient
 // of the residual branch (dy masked by the ReLU).
 extern "C" int ffa_bn_bwd(int dtype, const void* x, const void* dy, const void* y, const float* gamma,
-                          const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta,
+                          const float* beta, const float* mean, const float* rstd, void* dx, void* dres,
+                          float* dgamma, float* dbeta,
                           long long npix, int C, int relu, void* workspace, long long workspace_bytes,
                           hipStream_t stream) {
   FFA_REQUIRE(x && dy && dx && mean && rstd && dgamma && dbeta && workspace, "bn_bwd: null pointer");
-  FFA_REQUIRE(!relu || y, "bn_bwd: relu needs the forward output");
+  FFA_REQUIRE(relu >= 0 && relu <= 2, "bn_bwd: relu mode must be 0, 1 (mask from y) or 2 (mask from x)");
+  FFA_REQUIRE(relu != 1 || y, "bn_bwd: relu mode 1 needs the forward output");
   FFA_REQUIRE(C % 8 == 0 && C >= 8 && C <= 8 * FFA_EW_THREADS, "bn_bwd: unsupported channel count %d", C);
   if (workspace_bytes < ffa_bn_workspace_bytes(C)) {
     ffa_set_error("bn_bwd: workspace too small");
@@ -387,17 +417,18 @@ extern "C" int ffa_bn_bwd(int dtype, const void* x, const void* dy, const void* 
   float* coef = ws + (long long)FFA_MAX_PARTIALS * 2 * C;
   if (dtype == FFA_BF16) {
     hipLaunchKernelGGL((channel_reduce_kernel<ffa_bf16, BnBwdOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
-                       (const ffa_bf16*)x, (const ffa_bf16*)dy, (const ffa_bf16*)y, mean, rstd, ws, npix, C, relu);
+                       (const ffa_bf16*)x, (const ffa_bf16*)dy, (const ffa_bf16*)y, mean, rstd, gamma, beta, ws, npix, C,
+                       relu);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ffa_cdiv(C, 8)), dim3(FFA_FIN_THREADS), 0, stream, ws, nb, C, gamma,
-                       mean, rstd, inv_count, dgamma, dbeta, coef);
+                       beta, mean, rstd, inv_count, dgamma, dbeta, coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<ffa_bf16>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
                        (const ffa_bf16*)x, (const ffa_bf16*)dy, (const ffa_bf16*)y, coef, (ffa_bf16*)dx,
                        (ffa_bf16*)dres, nvec, C, relu);
   } else {
     hipLaunchKernelGGL((channel_reduce_kernel<float, BnBwdOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
-                       (const float*)x, (const float*)dy, (const float*)y, mean, rstd, ws, npix, C, relu);
+                       (const float*)x, (const float*)dy, (const float*)y, mean, rstd, gamma, beta, ws, npix, C, relu);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ffa_cdiv(C, 8)), dim3(FFA_FIN_THREADS), 0, stream, ws, nb, C, gamma,
-                       mean, rstd, inv_count, dgamma, dbeta, coef);
+                       beta, mean, rstd, inv_count, dgamma, dbeta, coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
                        (const float*)x, (const float*)dy, (const float*)y, coef, (float*)dx, (float*)dres, nvec, C,
                        relu);
@@ -545,14 +576,15 @@ extern "C" int ffa_channel_sums(int dtype, const void* x, long long npix, int C,
   float* ws = static_cast<float*>(workspace);
   if (dtype == FFA_BF16)
     hipLaunchKernelGGL((channel_reduce_kernel<ffa_bf16, StatOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
-                       (const ffa_bf16*)x, (const ffa_bf16*)nullptr, (const ffa_bf16*)nullptr, nullptr, nullptr, ws,
+                       (const ffa_bf16*)x, (const ffa_bf16*)nullptr, (const ffa_bf16*)nullptr, nullptr, nullptr, nullptr, nullptr, ws,
                        npix, C, 0);
   else
     hipLaunchKernelGGL((channel_reduce_kernel<float, StatOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
-                       (const float*)x, (const float*)nullptr, (const float*)nullptr, nullptr, nullptr, ws, npix, C, 0);
+                       (const float*)x, (const float*)nullptr, (const float*)nullptr, nullptr, nullptr, nullptr, nullptr, ws, npix,
+                       C, 0);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ffa_cdiv(C, 8)), dim3(FFA_FIN_THREADS), 0, stream, ws, nb, C,
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, sumsq_out, sum_out,
-                     (float*)nullptr);
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f,
+                     sumsq_out, sum_out, (float*)nullptr);
   return ffa_check_launch("channel_sums");
 }
 

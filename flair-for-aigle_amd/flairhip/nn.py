@@ -107,16 +107,18 @@ class _ConvBnAct(torch.autograd.Function):
         bn.note_batch()
         y = ops.bn_apply(y0, scale, shift, residual=residual, relu=relu)
         ctx.conv, ctx.relu, ctx.has_res = conv, relu, residual is not None
-        ctx.save_for_backward(x, y0, y if relu else None, gamma, mean, rstd)
+        # the forward output is kept for the ReLU mask only when a residual was added; otherwise the mask is
+        # recomputed from the pre-norm tensor (one fewer tensor read per backward pass, one fewer kept alive)
+        ctx.save_for_backward(x, y0, y if (relu and residual is not None) else None, gamma, beta, mean, rstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y0, y, gamma, mean, rstd = ctx.saved_tensors
+        x, y0, y, gamma, beta, mean, rstd = ctx.saved_tensors
         conv = ctx.conv
         dy = _as_nhwc_grad(dy)
         want_res = ctx.has_res and ctx.needs_input_grad[4]
-        d0, dres, dgamma, dbeta = ops.bn_bwd(y0, dy, y, gamma, mean, rstd, ctx.relu, want_res)
+        d0, dres, dgamma, dbeta = ops.bn_bwd(y0, dy, y, gamma, beta, mean, rstd, ctx.relu, want_res)
         dx = None
         if ctx.needs_input_grad[0]:
             pwt = conv.packed(x.dtype, transpose=True)

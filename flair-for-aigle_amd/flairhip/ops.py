@@ -187,9 +187,10 @@ def bn_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, residual
     return out
 
 
-def bn_bwd(x: torch.Tensor, dy: torch.Tensor, y: Optional[torch.Tensor], gamma, mean, rstd, relu: bool,
+def bn_bwd(x: torch.Tensor, dy: torch.Tensor, y: Optional[torch.Tensor], gamma, beta, mean, rstd, relu: bool,
            want_dres: bool):
-    """-> (dx, dres or None, dgamma, dbeta)."""
+    """-> (dx, dres or None, dgamma, dbeta).  With relu and y=None the ReLU mask is recomputed from x
+    (only valid when no residual was added before the ReLU)."""
     lib = _l.load()
     C_ = x.shape[-1]
     dev = x.device
@@ -197,9 +198,10 @@ def bn_bwd(x: torch.Tensor, dy: torch.Tensor, y: Optional[torch.Tensor], gamma, 
     dres = torch.empty_like(x) if want_dres else None
     dgb = torch.empty((2, C_), dtype=torch.float32, device=dev)
     ws = workspace(lib.ffa_bn_workspace_bytes(C_), dev, "bn")
-    _l.check(lib.ffa_bn_bwd(_dt(x), x.data_ptr(), dy.data_ptr(), _ptr(y), _ptr(gamma), mean.data_ptr(),
+    mode = 0 if not relu else (1 if y is not None else 2)
+    _l.check(lib.ffa_bn_bwd(_dt(x), x.data_ptr(), dy.data_ptr(), _ptr(y), _ptr(gamma), _ptr(beta), mean.data_ptr(),
                             rstd.data_ptr(), dx.data_ptr(), _ptr(dres), dgb[0].data_ptr(), dgb[1].data_ptr(),
-                            x.numel() // C_, C_, 1 if relu else 0, ws.data_ptr(), ws.numel(), _stream()), "bn_bwd")
+                            x.numel() // C_, C_, mode, ws.data_ptr(), ws.numel(), _stream()), "bn_bwd")
     return dx, dres, dgb[0], dgb[1]
 
 

@@ -72,9 +72,10 @@ int ffa_bn_eval_params(int C, const float* gamma, const float* beta, const float
                        const float* running_var, float eps, float* scale, float* shift, ffa_stream_t stream);
 int ffa_bn_apply(int dtype, const void* x, const void* residual, void* y, const float* scale, const float* shift,
                  long long npix, int C, int relu, ffa_stream_t stream);
-int ffa_bn_bwd(int dtype, const void* x, const void* dy, const void* y, const float* gamma, const float* mean,
-               const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, long long npix, int C, int relu,
-               void* workspace, long long workspace_bytes, ffa_stream_t stream);
+/* relu: 0 none, 1 mask from the stored output y, 2 mask recomputed from x (y may be null; no residual) */
+int ffa_bn_bwd(int dtype, const void* x, const void* dy, const void* y, const float* gamma, const float* beta,
+               const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, long long npix,
+               int C, int relu, void* workspace, long long workspace_bytes, ffa_stream_t stream);
 int ffa_channel_sums(int dtype, const void* x, long long npix, int C, float* sum_out, float* sumsq_out,
                      void* workspace, long long workspace_bytes, ffa_stream_t stream);
 int ffa_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int C,

@@ -240,7 +240,9 @@ def test_batchnorm_train(cuda, dtype, C, H, W, relu, res):
     y_ref2 = F.batch_norm(xq, None, None, gq, bq, training=True, eps=1e-5)
     (y_ref2 * (rq(dy, dtype) * mask)).sum().backward()
     dyd = to_nhwc(dy, dtype, cuda)
-    dx, dres, dgamma, dbeta = ops.bn_bwd(xd, dyd, y, gamma.to(cuda), mean, rstd, relu, res)
+    # residual layers mask with the stored output; plain conv-BN-ReLU layers recompute the mask from x
+    dx, dres, dgamma, dbeta = ops.bn_bwd(xd, dyd, y if res else None, gamma.to(cuda), beta.to(cuda), mean, rstd, relu,
+                                         res)
     torch.cuda.synchronize()
     assert (from_nhwc(dx, C) - xq.grad).abs().max().item() <= tol(dtype, xq.grad) * 4
     n = B * H * W
