@@ -494,6 +494,149 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_ring_kernel(WgradArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stem (7x7 stride 2, <= 16 stored input channels) weight gradient, bf16.  The generic kernel pads the 5 input
+// channels to a 32-channel plane (84 % of the MFMA columns wasted) and walks the 7 kernel rows as 7 separate
+// passes over the halo (5.9 GB staged per step, 0.95 ms).  Here one block stages the dy tile and the FULL
+// 21 x 37 halo once per 8 x 16 output tile and its eight waves split the work as 2 (32-channel co tiles) x 4 (kernel
+// row pairs); the 32 MFMA columns carry TWO taps x 16 channels: the transpose read takes a per-lane row address, so
+// the upper 16 lanes simply address the halo one pixel to the right.  Per (row, tap pair) one accumulator tile:
+// 2 rows x 4 pairs = 8 tiles = 128 accumulator registers per wave.
+
+template <int DUMMY>
+__global__ void __launch_bounds__(512, 2) stem_wgrad_kernel(WgradArgs a) {
+  constexpr int TH = 8, TW = 16, NPX = TH * TW, KS = NPX / 16;
+  constexpr int IH = (TH - 1) * 2 + 7, IW = (TW - 1) * 2 + 7;  // 21 x 37
+  constexpr int DY_ROWB = 64, IN_ROWB = 32;
+  constexpr int DY_BYTES = 2 * NPX * DY_ROWB;   // [2 co planes][128 px][32 co]
+  constexpr int IN_BYTES = IH * IW * IN_ROWB;   // [777 px][16 ch]
+  constexpr int DY_PIECES = DY_BYTES / 16, IN_PIECES = IN_BYTES / 16;
+  constexpr int NDP = (DY_PIECES + 511) / 512, NIP = (IN_PIECES + 511) / 512;
+  __shared__ __align__(16) unsigned char smem[DY_BYTES + IN_BYTES];
+  unsigned char* sDy = smem;
+  unsigned char* sIn = smem + DY_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = wave & 1, wr = wave >> 1;        // rows 2*wr, 2*wr+1 (wr == 3: row 6 only)
+  const int nrows = (wr == 3) ? 1 : 2;
+  const int cob = blockIdx.x, split = blockIdx.y;
+  const int co0 = cob * 64;
+  const int li = lane & 15, gsel = (lane >> 4) & 1, khalf = lane >> 5;
+
+  ffa_f32x16 acc[2][4];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[r][p][e] = 0.f;
+
+  const unsigned char* x_b = static_cast<const unsigned char*>(a.x);
+  const unsigned char* dy_b = static_cast<const unsigned char*>(a.dy);
+  ffa_u32x4 dreg[NDP], ireg[NIP];
+
+  auto load_tile = [&](int pt) {
+    const int tx = pt % a.tiles_x;
+    const int t2 = pt / a.tiles_x;
+    const int ty = t2 % a.tiles_y;
+    const int b = t2 / a.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * 2 - a.pad, ix0 = ox0 * 2 - a.pad;
+#pragma unroll
+    for (int k = 0; k < NDP; ++k) {
+      const int i = tid + k * 512;
+      const int part = i & 3, n = (i >> 2) % NPX, plane = i / (4 * NPX);
+      const int oy = oy0 + n / TW, ox = ox0 + n % TW;
+      const int c = co0 + plane * 32 + part * 8;
+      ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};
+      if (i < DY_PIECES && oy < a.Ho && ox < a.Wo && c < a.Co)
+        v = *reinterpret_cast<const ffa_u32x4*>(dy_b + (((size_t)(b * a.Ho + oy) * a.Wo + ox) * a.Co + c) * 2);
+      dreg[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NIP; ++k) {
+      const int i = tid + k * 512;
+      const int part = i & 1, q = i >> 1;
+      const int vy = iy0 + q / IW, vx = ix0 + q % IW;
+      ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};
+      if (i < IN_PIECES && vy >= 0 && vx >= 0 && vy < a.Hi && vx < a.Wi)
+        v = *reinterpret_cast<const ffa_u32x4*>(x_b + (((size_t)(b * a.Hi + vy) * a.Wi + vx) * a.Ci + part * 8) * 2);
+      ireg[k] = v;
+    }
+  };
+  auto tr2 = [&](const unsigned char* p0, int step) {
+    const ffa_s16x4 v0 = lds_read_tr16(p0);
+    const ffa_s16x4 v1 = lds_read_tr16(p0 + step);
+    ffa_u32x4 f;
+    f.x = __builtin_bit_cast(ffa_u32x2, v0).x;
+    f.y = __builtin_bit_cast(ffa_u32x2, v0).y;
+    f.z = __builtin_bit_cast(ffa_u32x2, v1).x;
+    f.w = __builtin_bit_cast(ffa_u32x2, v1).y;
+    return f;
+  };
+
+  int pt = split;
+  if (pt < a.npt) load_tile(pt);
+  for (; pt < a.npt; pt += a.nsplit) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NDP; ++k) {
+      const int i = tid + k * 512;
+      if (i < DY_PIECES) *reinterpret_cast<ffa_u32x4*>(sDy + (size_t)i * 16) = dreg[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NIP; ++k) {
+      const int i = tid + k * 512;
+      if (i < IN_PIECES) *reinterpret_cast<ffa_u32x4*>(sIn + (size_t)i * 16) = ireg[k];
+    }
+    __syncthreads();
+    if (pt + a.nsplit < a.npt) load_tile(pt + a.nsplit);
+
+    const unsigned char* aBase = sDy + wco * (NPX * DY_ROWB) + gsel * 32 + (li & 3) * 8;
+    // the upper 16 lanes (gsel = 1) carry the odd tap of the pair: one halo pixel to the right
+    const unsigned char* bBase = sIn + gsel * IN_ROWB + (li & 3) * 8;
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ++ks) {
+      const int n0 = ks * 16;
+      const int py = n0 / TW, px0 = n0 % TW;
+      const int prow = 8 * khalf + (li >> 2);  // output pixel of the k-step this lane addresses
+      const ffa_u32x4 af = tr2(aBase + (n0 + prow) * DY_ROWB, 4 * DY_ROWB);
+      const unsigned char* bk = bBase + ((py * 2) * IW + (px0 + prow) * 2) * IN_ROWB;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        if (r < nrows) {
+          const int kr = 2 * wr + r;
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const ffa_u32x4 bf = tr2(bk + (kr * IW + 2 * p) * IN_ROWB, 4 * 2 * IN_ROWB);
+            acc[r][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ffa_bf16x8, af),
+                                                                __builtin_bit_cast(ffa_bf16x8, bf), acc[r][p], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // slab [split][CoT][49][16]: column = lane & 31 -> tap 2p + (column >> 4), channel column & 15
+  const int col = lane & 31;
+  const int ci = col & 15, sodd = col >> 4;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (r >= nrows) continue;
+    const int kr = 2 * wr + r;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int s = 2 * p + sodd;
+      if (s >= 7) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wco * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        a.slabs[(((size_t)split * a.CoT + co) * 49 + kr * 7 + s) * 16 + ci] = acc[r][p][e];
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int nsplit, int CoT, int CiT, int Co,
                     int Ci, int taps, int accumulate) {
@@ -531,7 +674,7 @@ wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int
 // ------------------------------------------------------------------------------------------------
 
 struct WgradPlan {
-  int wco, wci, wk, th, tw, rg, nsplit, ncob, ncib, CoT, CiT, npt, tiles_x, tiles_y, ring, nslab;
+  int wco, wci, wk, th, tw, rg, nsplit, ncob, ncib, CoT, CiT, npt, tiles_x, tiles_y, ring, nslab, stem;
 };
 
 static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, int B, int Ho, int Wo, WgradPlan* p) {
@@ -562,6 +705,7 @@ static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, in
     p->wci = (f32 || stem) ? 1 : 2;
     if (stem && !f32) p->wk = 2;
   }
+  p->stem = (stem && !f32 && Ci <= 16 && Co % 64 == 0) ? 1 : 0;  // stem_wgrad_kernel
   p->ncob = ffa_cdiv(Co, 32 * p->wco);
   p->ncib = ffa_cdiv(Ci, 32 * p->wci);
   p->CoT = p->ncob * 32 * p->wco;
@@ -586,6 +730,14 @@ static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, in
   int ns = (p->ring || threads >= 512) ? 256 / tile_blocks : ffa_cdiv(512, tile_blocks);
   if (ns > p->npt) ns = p->npt;
   if (ns < 1) ns = 1;
+  if (p->stem) {  // one 512-thread block per CU, 64 output channels per block, 16-channel slabs
+    p->wk = 1;
+    p->CoT = Co;
+    p->CiT = 16;
+    ns = 256 / (Co / 64);
+    if (ns > p->npt) ns = p->npt;
+    if (ns < 1) ns = 1;
+  }
   p->nsplit = ns;
   const bool merge = p->wk > 1 && (p->wco * p->wci == 4 || stem);  // mirrors WgradGeom::MERGE
   p->nslab = merge ? ns : ns * p->wk;
@@ -645,6 +797,12 @@ static int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int kh, int kw, 
     launch_wgrad_cfg<T, 1, 1, 1, 1, 2, F32 ? 1 : 2, 1, 4, 16>(a, 1, stream);
     return ffa_check_launch("conv_wgrad");
   } else if (kh == 7) {
+    if constexpr (!F32) {
+      if (p.stem) {
+        hipLaunchKernelGGL((stem_wgrad_kernel<0>), dim3(a.Co / 64, a.nsplit), dim3(512), 0, stream, a);
+        return ffa_check_launch("stem_wgrad");
+      }
+    }
     launch_wgrad_cfg<T, 7, 7, 2, 1, 2, 1, F32 ? 1 : 2, 8, 16>(a, 7, stream);
     return ffa_check_launch("conv_wgrad");
   }
