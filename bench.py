@@ -186,13 +186,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # FFA_BENCH_BACKEND=gloo lets the multi-rank flow be rehearsed on a one-GPU box (ranks then share cuda:0)
+    backend = os.environ.get("FFA_BENCH_BACKEND", "nccl")
+    local_dev = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL; one process per GPU
+        else:
+            dist.init_process_group(backend)
 
     from flairhip.configs import unet_resnet34_config
     from flairhip.distributed import GradSync
