@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
                              (size_t)cb * a.nchunks * G::NRG * (size_t)(BCO * G::TAPS * 32);
   const int total_chunks = a.nchunks * G::NRG;
 
-  ffa_u32x4 wreg[G::NWP];
+  ffa_u32x4 wregA[G::NWP], wregB[G::NWP];  // weight slabs of chunk c+1 / c+2 in flight (prefetch distance 2)
   ffa_u32x4 hreg[G::NHP];
 
   // halo piece geometry, computed once: byte offset from the input base (32-bit: the host checks the tensor is
@@ -176,12 +176,12 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
     hlds[k] = q * G::PP + hh * 16;
   }
 
-#define FFA_LOAD_W(c_)                                                                                       \
+#define FFA_LOAD_W(c_, WR)                                                                                   \
   {                                                                                                          \
     const ffa_u32x4* wsrc_ = reinterpret_cast<const ffa_u32x4*>(w_b + (size_t)(c_) * (BCO * G::TAPS * 32)); \
     _Pragma("unroll") for (int k = 0; k < G::NWP; ++k) {                                                     \
       const int i = tid + k * G::NTHR;                                                                       \
-      wreg[k] = wsrc_[(G::W_PIECES % G::NTHR == 0 || i < G::W_PIECES) ? i : 0];                              \
+      WR[k] = wsrc_[(G::W_PIECES % G::NTHR == 0 || i < G::W_PIECES) ? i : 0];                                \
     }                                                                                                        \
   }
   /* c_ = chunk whose halo is needed: channel bytes (c_/NRG/HK)*HK*32 .., kernel rows (c_ % NRG)*RG ..
@@ -223,13 +223,13 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
       }                                                                                                      \
     }                                                                                                        \
   }
-#define FFA_STORE_W()                                                                      \
+#define FFA_STORE_W(WR)                                                                    \
   {                                                                                        \
     _Pragma("unroll") for (int k = 0; k < G::NWP; ++k) {                                   \
       const int i = tid + k * G::NTHR;                                                     \
       if (G::W_PIECES % G::NTHR == 0 || i < G::W_PIECES) {                                 \
         const int row = i / (G::TAPS * 2), col = i % (G::TAPS * 2);                        \
-        *reinterpret_cast<ffa_u32x4*>(sW + row * G::WP + col * 16) = wreg[k];              \
+        *reinterpret_cast<ffa_u32x4*>(sW + row * G::WP + col * 16) = WR[k];                \
       }                                                                                    \
     }                                                                                      \
   }
@@ -242,20 +242,8 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
     }                                                                                      \
   }
 
-  FFA_LOAD_W(0)
-  FFA_LOAD_H(0)
-  FFA_STORE_W()
-  FFA_STORE_H()
-  __syncthreads();
-
-  for (int c = 0; c < total_chunks; ++c) {
-    const bool more = (c + 1 < total_chunks);
-    // the halo is refilled when the next chunk starts a new group of HK channel k-steps (or a new row group)
-    const bool more_h = more && (G::NRG > 1 || ((c + 1) % HK) == 0);
-    const int sub = (G::NRG > 1) ? 0 : (c % HK) * 32;  // byte offset of this chunk's k-step inside a halo pixel
-    if (more) FFA_LOAD_W(c + 1)  // global loads stay in flight under the MFMAs below
-    if (more_h) FFA_LOAD_H(c + 1)
-
+  // one chunk of matrix work from the LDS images; `sub` = byte offset of the chunk's k-step inside a halo pixel
+  auto compute = [&](int sub) __attribute__((always_inline)) {
     // fragments are double-buffered in registers: the ds_reads of tap t+1 are issued before the MFMAs of
     // tap t, so their LDS latency hides under the matrix pipe instead of stalling every tap
     ffa_u32x4 af[2][G::MT], bf[2][G::NT];
@@ -293,14 +281,38 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
         if (NR > NM) __builtin_amdgcn_sched_group_barrier(0x100, NR - NM, 0);
       }
     }
-    __syncthreads();
-    if (more) {
-      FFA_STORE_W()
-      if (more_h) FFA_STORE_H()
-      __syncthreads();
-    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // Halo refills are issued HD chunks before they are stored (deep staging: three chunks of matrix work to land
+  // under), weight slabs two chunks ahead (two register sets, loop unrolled by two)
+  constexpr int HD = (HK >= 4 && G::NRG == 1) ? 3 : 1;
+#define FFA_CHUNK(c_, WCUR, WNXT)                                                                            \
+  {                                                                                                          \
+    const int cq_ = (c_);                                                                                    \
+    if (cq_ + 2 < total_chunks) FFA_LOAD_W(cq_ + 2, WNXT)                                                    \
+    if (cq_ + HD < total_chunks && (G::NRG > 1 || ((cq_ + HD) % HK) == 0)) FFA_LOAD_H(cq_ + HD)              \
+    compute((G::NRG > 1) ? 0 : (cq_ % HK) * 32);                                                             \
+    __syncthreads();                                                                                         \
+    if (cq_ + 1 < total_chunks) {                                                                            \
+      FFA_STORE_W(WCUR)                                                                                      \
+      if (G::NRG > 1 || ((cq_ + 1) % HK) == 0) FFA_STORE_H()                                                 \
+      __syncthreads();                                                                                       \
+    }                                                                                                        \
   }
 
+  FFA_LOAD_W(0, wregA)
+  FFA_LOAD_H(0)
+  FFA_STORE_W(wregA)
+  FFA_STORE_H()
+  __syncthreads();
+  if (total_chunks > 1) FFA_LOAD_W(1, wregA)
+  for (int c = 0; c < total_chunks; c += 2) {
+    FFA_CHUNK(c, wregA, wregB)
+    if (c + 1 < total_chunks) FFA_CHUNK(c + 1, wregB, wregA)
+  }
+
+#undef FFA_CHUNK
 #undef FFA_LOAD_W
 #undef FFA_LOAD_H
 #undef FFA_STORE_W
@@ -397,7 +409,6 @@ static bool conv_supported(int kh, int kw, int stride, int bco) {
   const bool shape = (kh == 3 && kw == 3 && (stride == 1 || stride == 2)) ||
                      (kh == 1 && kw == 1 && (stride == 1 || stride == 2)) || (kh == 7 && kw == 7 && stride == 2);
   if (!shape) return false;
-  if (bco == 128) return kh == 3 && stride == 1;
   return bco == 64 || bco == 32;
 }
 
@@ -411,9 +422,10 @@ static int launch_hk(const ConvArgs& a, hipStream_t stream) {
 
 template <typename T, int KH, int KW, int STRIDE, int RG, int BCO, int WCO, int WPX, int TH, int TW>
 static int launch_cfg(const ConvArgs& a, hipStream_t stream) {
-  // deep halo staging for the 3x3 stride-1 workhorse when whole 64- / 128-byte runs of channels exist;
-  // the 128-row block keeps HK = 1 (its weight slab leaves no LDS for a deeper halo at two blocks per CU)
-  if constexpr (KH == 3 && STRIDE == 1 && BCO <= 64) {
+  // deep halo staging for the 3x3 stride-1 workhorse when whole 64- / 128-byte runs of channels exist
+  // (a 128-row block was measured equal at best: its weight slab leaves no LDS for the deep halo at two blocks
+  // per CU, so 64 rows is the largest block instantiated)
+  if constexpr (KH == 3 && STRIDE == 1) {
     if (a.nchunks % 4 == 0) return launch_hk<T, KH, KW, STRIDE, RG, BCO, WCO, WPX, TH, TW, 4>(a, stream);
     if (a.nchunks % 2 == 0) return launch_hk<T, KH, KW, STRIDE, RG, BCO, WCO, WPX, TH, TW, 2>(a, stream);
   }
@@ -427,9 +439,6 @@ static int launch_shape(const ConvArgs& a, const ConvPlan& p, hipStream_t stream
   if (p.bco == BCO_) {                                                                       \
     return wide ? launch_cfg<T, KH, KW, STRIDE, RG, BCO_, WCO_, WPX_, 8, 32>(a, stream)      \
                 : launch_cfg<T, KH, KW, STRIDE, RG, BCO_, WCO_, WPX_, 16, 16>(a, stream);    \
-  }
-  if constexpr (KH == 3 && STRIDE == 1) {
-    FFA_CONV_CASE(128, 2, 2)
   }
   FFA_CONV_CASE(64, 1, 4)
   FFA_CONV_CASE(32, 1, 4)
