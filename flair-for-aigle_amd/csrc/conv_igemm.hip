@@ -602,3 +602,94 @@ extern "C" int ffa_pack_conv_weight(int dtype, const float* w_oihw, const float*
     hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, stream, p);
   return ffa_check_launch("pack_weight");
 }
+
+// ------------------------------------------------------------------------------------------------
+// batched packing: every conv weight of the network (forward and dgrad operands) in ONE launch per step.
+// The descriptor table lives in device memory and is built once (ffa_pack_desc_fill on the host, then copied);
+// blockIdx.y selects the descriptor, blockIdx.x strides over its elements.
+
+__device__ __forceinline__ void pack_one(const PackArgs& p, long long i, int dtype) {
+  const int EPC = (dtype == FFA_BF16) ? 16 : 8;
+  const int taps = p.rg * p.kw;
+  const int nrg = p.kh / p.rg;
+  long long t = i;
+  const int e = t % EPC; t /= EPC;
+  const int tap = t % taps; t /= taps;
+  const int row_l = t % p.bco; t /= p.bco;
+  const int rg = t % nrg; t /= nrg;
+  const int cc = t % p.nchunks; t /= p.nchunks;
+  const int cb = (int)t;
+  int row_in_block = row_l;
+  if (p.bco >= 64) {
+    const int j = row_l & 63, mt = j >> 5, rho = j & 31;
+    row_in_block = (row_l & ~63) + 16 * (rho >> 3) + 8 * ((rho >> 2) & 1) + 4 * mt + (rho & 3);
+  }
+  const int row = cb * p.bco + row_in_block;
+  const int ch = cc * EPC + e;
+  int r = rg * p.rg + tap / p.kw;
+  int sx = tap % p.kw;
+  float v = 0.f;
+  if (row < p.rows && ch < p.chs) {
+    if (p.flip) {
+      r = p.kh - 1 - r;
+      sx = p.kw - 1 - sx;
+    }
+    v = p.src[row * p.s_row + ch * p.s_ch + r * p.kw + sx];
+    if (p.scale) v *= p.scale[row];
+  }
+  if (dtype == FFA_BF16)
+    ffa_store_elem<ffa_bf16>(static_cast<ffa_bf16*>(p.dst) + i, v);
+  else
+    ffa_store_elem<float>(static_cast<float*>(p.dst) + i, v);
+}
+
+__global__ void pack_weight_batched_kernel(const PackArgs* __restrict__ descs, int dtype) {
+  const PackArgs p = descs[blockIdx.y];
+  const int EPC = (dtype == FFA_BF16) ? 16 : 8;
+  const long long total = (long long)p.ncb * p.nchunks * (p.kh / p.rg) * p.bco * (p.rg * p.kw) * EPC;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x)
+    pack_one(p, i, dtype);
+}
+
+extern "C" int ffa_pack_desc_bytes(void) { return (int)sizeof(PackArgs); }
+
+// Fills one HOST descriptor (same arguments as ffa_pack_conv_weight, pointers are device pointers).
+extern "C" int ffa_pack_desc_fill(void* host_desc, const float* w_oihw, const float* scale, void* dst, int O, int I,
+                                  int kh, int kw, int transpose, int co_rows, int ci_pitch, int bco, int rg,
+                                  int dtype) {
+  FFA_REQUIRE(host_desc && w_oihw && dst, "pack_desc_fill: null pointer");
+  FFA_REQUIRE(bco > 0 && co_rows % bco == 0 && rg > 0 && kh % rg == 0 && ci_pitch % 16 == 0,
+              "pack_desc_fill: bad geometry");
+  PackArgs p;
+  memset(&p, 0, sizeof(p));
+  p.src = w_oihw;
+  p.dst = dst;
+  p.scale = scale;
+  if (!transpose) {
+    p.rows = O; p.chs = I;
+    p.s_row = (long long)I * kh * kw;
+    p.s_ch = (long long)kh * kw;
+    p.flip = 0;
+  } else {
+    p.rows = I; p.chs = O;
+    p.s_row = (long long)kh * kw;
+    p.s_ch = (long long)I * kh * kw;
+    p.flip = 1;
+  }
+  FFA_REQUIRE(p.rows <= co_rows && p.chs <= ci_pitch, "pack_desc_fill: padded dims smaller than the tensor");
+  p.kh = kh; p.kw = kw; p.rg = rg; p.bco = bco;
+  p.nchunks = ci_pitch / ((dtype == FFA_BF16) ? 16 : 8);
+  p.ncb = co_rows / bco;
+  memcpy(host_desc, &p, sizeof(p));
+  return FFA_OK;
+}
+
+extern "C" int ffa_pack_conv_weights_batched(int dtype, const void* descs_device, int n, hipStream_t stream) {
+  FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "pack_batched: bad dtype");
+  FFA_REQUIRE(descs_device && n > 0 && n <= 65535, "pack_batched: bad descriptor table");
+  // 256 blocks per descriptor: the largest operands (2.4 M elements) set the tail, small ones exit at once
+  hipLaunchKernelGGL(pack_weight_batched_kernel, dim3(256, n), dim3(256), 0, stream,
+                     static_cast<const PackArgs*>(descs_device), dtype);
+  return ffa_check_launch("pack_weight_batched");
+}

@@ -290,22 +290,24 @@ __global__ void ce_weight_sum_kernel(const uint8_t* __restrict__ tgt, const floa
   }
 }
 
+// one wave; lane l adds partials l, l+64, ... in double, then a fixed xor-shuffle tree: reproducible order
+__device__ __forceinline__ double ce_sum_partials(const float* __restrict__ parts, int n) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += (double)parts[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  return s;
+}
+
 __global__ void ce_finalize_sum_kernel(const float* __restrict__ parts, int n, float* __restrict__ out) {
-  // single thread, fixed order -> bitwise reproducible
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < n; ++i) s += (double)parts[i];
-    out[0] = (float)s;
-  }
+  const double s = ce_sum_partials(parts, n);
+  if (threadIdx.x == 0) out[0] = (float)s;
 }
 
 __global__ void ce_finalize_loss_kernel(const float* __restrict__ parts, int n, const float* __restrict__ wsum,
                                         float* __restrict__ loss) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < n; ++i) s += (double)parts[i];
-    loss[0] = (float)(s / (double)wsum[0]);
-  }
+  const double s = ce_sum_partials(parts, n);
+  if (threadIdx.x == 0) loss[0] = (float)(s / (double)wsum[0]);
 }
 
 template <typename T>

@@ -114,6 +114,7 @@ class FLAIR_HUB_Model(nn.Module):
             self.main_decoders[task] = FLAIR_Monotemp(
                 config, channels=1, classes=len(config["labels_configs"][task]["value_name"]), return_type="decoder")
         self.aux_decoders = nn.ModuleDict()
+        self._pack_plan = hnn.PackPlan(self)
         self._log_parameter_table()
 
     # ---- helpers ---------------------------------------------------------------------------------
@@ -147,6 +148,8 @@ class FLAIR_HUB_Model(nn.Module):
 
     def forward(self, batch: dict, apply_mod_dropout: bool = False) -> Tuple[Dict[str, torch.Tensor], Dict]:
         labels = self.config["labels"]
+        if self.training:
+            self._pack_plan.refresh(self.compute_dtype)  # all conv operands re-packed in one launch per step
         fmaps: Dict[str, list] = {}
         first_mod = next(iter(self.encoders))
         # the reference learns the output size from the label tensor (:371); the zonal dataset fabricates a

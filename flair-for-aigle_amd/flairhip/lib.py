@@ -44,6 +44,9 @@ SIGNATURES = {
     "ffa_conv_row_group": (_i, [_i]),
     "ffa_pack_conv_weight_bytes": (_ll, [_i, _i, _i, _i, _i]),
     "ffa_pack_conv_weight": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "ffa_pack_desc_bytes": (_i, []),
+    "ffa_pack_desc_fill": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "ffa_pack_conv_weights_batched": (_i, [_i, _p, _i, _p]),
     "ffa_conv2d": (_i, [_i, _p, _p, _p, _p, _p] + [_i] * 15 + [_p]),
     "ffa_conv_wgrad_workspace_bytes": (_ll, [_i] * 9),
     "ffa_conv_wgrad": (_i, [_i, _p, _p, _p] + [_i] * 14 + [_p, _ll, _p]),

@@ -65,6 +65,44 @@ class HipConv2d(nn.Module):
                 f"padding={self.padding}, bias={self.bias is not None}")
 
 
+class PackPlan:
+    """Keeps the MFMA operands of all conv layers of a module tree current with ONE kernel launch per optimizer
+    step (93 separate pack launches cost 0.5 ms per step at batch 32).  Layers enter the plan once they have been
+    packed individually (first forward / backward), so unused layers never do."""
+
+    def __init__(self, root: nn.Module):
+        self.convs = [m for m in root.modules() if isinstance(m, HipConv2d)]
+        self.batch = None
+        self.sig = None       # identity of the buffers the table points at
+        self.versions = None  # parameter versions the packed operands correspond to
+
+    def refresh(self, dtype: torch.dtype) -> None:
+        entries, sig, slots = [], [], []
+        for c in self.convs:
+            for transpose in (False, True):
+                hit = c._cache.get((dtype, transpose, ""))
+                if hit is None:
+                    continue
+                entries.append((c.weight.detach(), hit[1], transpose))
+                sig.append((c.weight.data_ptr(), hit[1].data.data_ptr()))
+                slots.append((c, transpose))
+        if not entries:
+            return
+        versions = [c.weight._version for c, _ in slots]
+        if self.batch is None or sig != self.sig:
+            if not all(e[0].is_contiguous() for e in entries):
+                return
+            self.batch, self.sig, self.versions = ops.PackBatch(entries, dtype), sig, None
+        stale = [i for i, (c, tr) in enumerate(slots)
+                 if c._cache[(dtype, tr, "")][0][0] != versions[i]]
+        if not stale:
+            return
+        self.batch.run()
+        for (c, tr), v in zip(slots, versions):
+            key = (dtype, tr, "")
+            c._cache[key] = ((v, c.weight.data_ptr(), None), c._cache[key][1])
+
+
 class HipBatchNorm2d(nn.Module):
     """Parameter / buffer holder mirroring nn.BatchNorm2d (eps 1e-5, momentum 0.1)."""
 

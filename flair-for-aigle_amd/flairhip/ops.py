@@ -98,6 +98,34 @@ def pack_conv_weight(w_oihw: torch.Tensor, dtype: torch.dtype, stride: int, ci_p
     return PackedWeight(dst, rows, rows_real, ci_pitch, bco, kh, kw, use_stride, O if transpose else I)
 
 
+class PackBatch:
+    """Descriptor table for ffa_pack_conv_weights_batched: re-packs many conv operands in one launch.
+
+    entries: (master weight OIHW f32, PackedWeight it feeds, transpose flag).  The table holds raw device
+    pointers, so it must be rebuilt when a parameter or a packed buffer is re-allocated."""
+
+    def __init__(self, entries, dtype: torch.dtype):
+        lib = _l.load()
+        self.dtype_id = _dtype_id(dtype)
+        self.n = len(entries)
+        nb = lib.ffa_pack_desc_bytes()
+        host = C.create_string_buffer(nb * self.n)
+        base = C.addressof(host)
+        self.keep = []
+        for i, (w, pw, transpose) in enumerate(entries):
+            O, I, kh, kw = w.shape
+            _l.check(lib.ffa_pack_desc_fill(base + i * nb, w.data_ptr(), None, pw.data.data_ptr(), O, I, kh, kw,
+                                            1 if transpose else 0, pw.rows, pw.ci_pitch, pw.bco,
+                                            lib.ffa_conv_row_group(kh), self.dtype_id), "pack_desc_fill")
+            self.keep.append((w, pw))
+        self.table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(entries[0][0].device)
+
+    def run(self) -> None:
+        lib = _l.load()
+        _l.check(lib.ffa_pack_conv_weights_batched(self.dtype_id, self.table.data_ptr(), self.n, _stream()),
+                 "pack_conv_weights_batched")
+
+
 def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:
     return (h + 2 * pad - k) // stride + 1
 

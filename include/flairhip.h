@@ -52,6 +52,12 @@ long long ffa_pack_conv_weight_bytes(int dtype, int co_rows, int ci_pitch, int k
  * channels, taps mirrored).  scale (optional, per row) folds an eval-mode BatchNorm. */
 int ffa_pack_conv_weight(int dtype, const float* w_oihw, const float* scale, void* dst, int O, int I, int kh, int kw,
                          int transpose, int co_rows, int ci_pitch, int bco, int rg, ffa_stream_t stream);
+/* every conv operand of a network in one launch: descriptors are filled on the host (ffa_pack_desc_fill,
+ * ffa_pack_desc_bytes each), copied to the device once, and replayed every step */
+int ffa_pack_desc_bytes(void);
+int ffa_pack_desc_fill(void* host_desc, const float* w_oihw, const float* scale, void* dst, int O, int I, int kh,
+                       int kw, int transpose, int co_rows, int ci_pitch, int bco, int rg, int dtype);
+int ffa_pack_conv_weights_batched(int dtype, const void* descs_device, int n, ffa_stream_t stream);
 /* out = relu?( conv(in, w) + bias + residual ).  dil=2 reads `in` through a virtual zero insertion
  * (dgrad of a stride-2 layer, stride must then be 1). */
 int ffa_conv2d(int dtype, const void* in, const void* w_packed, const float* bias, const void* residual, void* out,
