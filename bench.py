@@ -181,6 +181,7 @@ def main():
     ap.add_argument("--tile", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-symbol table to stderr")
+    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of as one hipGraph replay")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -206,7 +207,7 @@ def main():
 
     total_steps = args.steps + args.warmup
     cfg = unet_resnet34_config(in_channels=5, precision=args.precision, batch_size=args.batch,
-                               total_steps=max(total_steps, 10))
+                               total_steps=total_steps + 16)  # + graph warm-up and roofline-pass steps
     torch.manual_seed(cfg["hyperparams"]["seed"])
     task = build_segmentation_module(cfg, {MOD: args.tile}, "train").to(dev)
     task.train()
@@ -223,7 +224,7 @@ def main():
     timer = KernelTimer()
     timer.install()
 
-    def step(i):
+    def eager_step(i):
         loss = task.training_step(batch, i)
         optimizer.zero_grad(set_to_none=True)
         loss.backward()
@@ -232,12 +233,25 @@ def main():
         scheduler.step()
         return loss
 
+    # single process: the whole step (forward, loss, metrics, backward, AdamW) is one hipGraph replay;
+    # multi process: eager, the RCCL all-reduces are issued from autograd hooks (flairhip.distributed)
+    use_graph = (world == 1) and not args.no_graph
+    graphed = None
+    if use_graph:
+        from flairhip.graph import GraphedTrainStep
+        try:
+            graphed = GraphedTrainStep(task, optimizer, batch, warmup_steps=3, after_step=scheduler.step)
+        except Exception as e:  # capture is an optimisation, never a requirement
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            use_graph = False
+    step = (lambda i: graphed(batch)) if use_graph else eager_step
+
     for i in range(args.warmup):
         step(i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
+    timer.enabled = not use_graph  # HIP events cannot time kernels inside a graph replay: see below
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
@@ -246,6 +260,17 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    roof_steps = args.steps
+    if use_graph:
+        # roofline pass: the same step run eagerly a few times with HIP events around every MFMA kernel launch
+        final_loss_t = loss.detach().clone()
+        roof_steps = 3
+        timer.enabled = True
+        for i in range(roof_steps):
+            eager_step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        timer.enabled = False
+        loss = final_loss_t
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -259,15 +284,15 @@ def main():
         dom = max(summ.items(), key=lambda kv: kv[1]["seconds"])
         peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
         ach = dom[1]["flops"] / dom[1]["seconds"] / 1e12
-        mfma_total = sum(v["seconds"] for v in summ.values())
+        mfma_total = sum(v["seconds"] for v in summ.values()) * (args.steps / roof_steps)
         roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom[0]),
-                    "launches_per_step": dom[1]["launches"] / args.steps,
+                    "launches_per_step": dom[1]["launches"] / roof_steps,
                     "avg_launch_ms": round(dom[1]["seconds"] / dom[1]["launches"] * 1e3, 4),
                     "mfma_kernels_share_of_step": round(mfma_total / elapsed, 4)}
         if args.breakdown:
             for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"]):
-                print(f"  {k:62s} {v['seconds'] / args.steps * 1e3:8.3f} ms/step {v['launches'] // args.steps:4d} launches "
+                print(f"  {k:62s} {v['seconds'] / roof_steps * 1e3:8.3f} ms/step {v['launches'] // roof_steps:4d} launches "
                       f"{v['flops'] / v['seconds'] / 1e12:8.1f} TFLOP/s", file=sys.stderr)
             print(f"  MFMA kernels total {mfma_total / args.steps * 1e3:.3f} ms of {ms:.3f} ms/step; loss {final_loss:.4f}",
                   file=sys.stderr)
@@ -279,7 +304,7 @@ def main():
             "config": {"workload": f"synthetic {S}x{S}x5 tiles, 19-class U-Net (ResNet-34 encoder), batch {B} per GPU, "
                                    f"train step (BASELINE.json configs[{1 if world == 1 else 2}])",
                        "global_batch": B * world, "tile": S, "parallelism": f"dp{world}"},
-            "final_loss": round(final_loss, 5),
+            "final_loss": round(final_loss, 5), "hip_graph": bool(use_graph),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -545,3 +545,37 @@ extern "C" int ffa_onehot_to_index(const float* onehot, uint8_t* idx, int B, int
                      (long long)H * W);
   return ffa_check_launch("onehot_to_index");
 }
+
+// ------------------------------------------------------------------------------------------------
+// K x K confusion matrix of uint8 predictions vs uint8 targets, accumulated into int64 counts
+// (rows = target, columns = prediction): the state behind the IoU metrics that the reference's
+// training_step / validation_step update every batch (flair_hub/tasks/tasks_module.py:210-212, :273-275 via
+// torchmetrics).  Block-local histogram in LDS, one integer atomic per non-empty bin per block: exact,
+// order independent, no host synchronisation (torch.bincount needs one, which would break graph capture).
+
+__global__ void __launch_bounds__(FFA_EW_THREADS)
+confusion_kernel(const uint8_t* __restrict__ pred, const uint8_t* __restrict__ tgt, long long n, int K,
+                 unsigned long long* __restrict__ out) {
+  __shared__ unsigned int hist[FFA_CE_MAXK * FFA_CE_MAXK];
+  const int bins = K * K;
+  for (int i = threadIdx.x; i < bins; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int t = tgt[i], p = pred[i];
+    if (t < K && p < K) atomicAdd(&hist[t * K + p], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < bins; i += blockDim.x)
+    if (hist[i]) atomicAdd(&out[i], (unsigned long long)hist[i]);
+}
+
+extern "C" int ffa_confusion_matrix(const uint8_t* pred, const uint8_t* target, long long n, int K, long long* counts,
+                                    hipStream_t stream) {
+  FFA_REQUIRE(pred && target && counts && K >= 1 && K <= FFA_CE_MAXK, "confusion_matrix: bad arguments");
+  long long nb = (n + FFA_EW_THREADS * 16 - 1) / (FFA_EW_THREADS * 16);
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(confusion_kernel, dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream, pred, target, n, K,
+                     reinterpret_cast<unsigned long long*>(counts));
+  return ffa_check_launch("confusion_matrix");
+}

@@ -19,6 +19,11 @@ class MulticlassJaccardIndex(nn.Module):
     @torch.no_grad()
     def update(self, preds: torch.Tensor, target: torch.Tensor) -> None:
         k = self.num_classes
+        if (preds.is_cuda and preds.dtype == torch.uint8 and target.dtype == torch.uint8 and k <= 32
+                and preds.is_contiguous() and target.is_contiguous() and self.confmat.is_cuda):
+            from flairhip import ops  # block-local LDS histogram kernel: exact, no host synchronisation
+            ops.confusion_matrix_update(self.confmat, preds, target)
+            return
         idx = target.reshape(-1).long() * k + preds.reshape(-1).long()
         self.confmat += torch.bincount(idx, minlength=k * k).view(k, k).to(self.confmat.device)
 

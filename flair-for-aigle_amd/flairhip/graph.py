@@ -1,0 +1,86 @@
+"""Whole-step hipGraph capture.
+
+A batch-32 training step is ~900 kernel launches (conv / BN / pool / loss forward and backward, optimizer);
+the kernels sum to 19.8 ms but eager dispatch leaves ~1 ms of gaps, and at the zonal loop's batch 8 the step is
+launch-bound outright.  Every libflairhip entry point launches on the caller's stream without allocating or
+synchronising, so the whole step -- SegmentationTask.training_step (forward, fused loss, metric update),
+backward and the optimizer -- can be captured once into a HIP graph and replayed per batch: static shapes,
+static buffers, one launch per step.  The learning-rate schedule stays on the host and writes the next value
+into the optimizer's device-resident ``lr`` tensor between replays.
+
+Single-process only: with world size > 1 the gradient all-reduce is issued from autograd hooks
+(flairhip.distributed.GradSync) and the step runs eagerly.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+
+from . import nn as hnn
+
+
+def make_capturable(optimizer: torch.optim.Optimizer) -> None:
+    """Adam / AdamW: device-resident step counters and learning rate, as graph capture requires."""
+    for g in optimizer.param_groups:
+        if "capturable" in g:
+            g["capturable"] = True
+        if not torch.is_tensor(g["lr"]):
+            dev = g["params"][0].device
+            g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=dev)
+        if "initial_lr" in g and torch.is_tensor(g["initial_lr"]):
+            g["initial_lr"] = float(g["initial_lr"])
+
+
+class GraphedTrainStep:
+    """step(batch) -> loss tensor (static buffer, valid until the next call)."""
+
+    def __init__(self, task, optimizer: torch.optim.Optimizer, example_batch: Dict[str, torch.Tensor],
+                 warmup_steps: int = 3, after_step: Optional[Callable[[], None]] = None):
+        self.task, self.optimizer, self.after_step = task, optimizer, after_step
+        self.static_batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
+        self._bns = [m for m in task.modules() if isinstance(m, hnn.HipBatchNorm2d)]
+        make_capturable(optimizer)
+
+        # warm-up on a side stream: sizes every workspace, fills the weight-pack plan, creates optimizer state
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(warmup_steps):
+                self._eager_step(i)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.warmup_steps = warmup_steps
+
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        pending = [bn._pending_batches for bn in self._bns]
+        with torch.cuda.graph(self.graph):
+            loss = task.training_step(self.static_batch, 0)
+            loss.backward()
+            optimizer.step()
+        self.loss = loss
+        for bn, n in zip(self._bns, pending):  # capture ran the Python but not the kernels
+            bn._pending_batches = n
+
+    def _eager_step(self, i: int):
+        loss = self.task.training_step(self.static_batch, i)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.optimizer.step()
+        if self.after_step is not None:
+            self.after_step()
+        return loss
+
+    def __call__(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                dst = self.static_batch[k]
+                if dst.data_ptr() != v.data_ptr():
+                    dst.copy_(v, non_blocking=True)
+        self.graph.replay()
+        for bn in self._bns:  # host-side bookkeeping the replay skips
+            bn.note_batch()
+        if self.after_step is not None:
+            self.after_step()
+        return self.loss

@@ -69,6 +69,7 @@ SIGNATURES = {
     "ffa_softmax_ce": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p, _ll, _p]),
     "ffa_predict_u8": (_i, [_i, _i, _p, _p] + [_i] * 9 + [_p]),
     "ffa_onehot_to_index": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "ffa_confusion_matrix": (_i, [_p, _p, _ll, _i, _p, _p]),
     "ffa_slice_grid": (_ll, [_d, _d, _d, _d, _d, _d, _i, _i, _d, C.POINTER(Tile), _ll]),
     "ffa_write_window": (_i, [_d, _d, _d, _d, _d, _d, _d, _i, _i, C.POINTER(Window)]),
     "ffa_probe_tr16": (_i, [_p, _p, _p]),

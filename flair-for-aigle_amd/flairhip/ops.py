@@ -401,6 +401,17 @@ def onehot_to_index(onehot: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def confusion_matrix_update(counts: torch.Tensor, pred: torch.Tensor, target: torch.Tensor) -> None:
+    """counts[target, pred] += 1 for uint8 class maps (counts: int64 [K, K], updated in place, no host sync)."""
+    lib = _l.load()
+    if pred.dtype != torch.uint8 or target.dtype != torch.uint8 or not (pred.is_contiguous() and target.is_contiguous()):
+        raise ValueError("confusion_matrix_update: pred / target must be contiguous uint8 tensors")
+    if counts.dtype != torch.int64 or counts.dim() != 2 or counts.shape[0] != counts.shape[1]:
+        raise ValueError("confusion_matrix_update: counts must be int64 [K, K]")
+    _l.check(lib.ffa_confusion_matrix(pred.data_ptr(), target.data_ptr(), pred.numel(), counts.shape[0],
+                                      counts.data_ptr(), _stream()), "confusion_matrix")
+
+
 # --------------------------------------------------------------------------------------------------
 # host-side tile bookkeeping (no GPU involved)
 

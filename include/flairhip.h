@@ -115,6 +115,9 @@ int ffa_softmax_ce(int dtype, const void* logits, const uint8_t* targets, const 
 int ffa_predict_u8(int dtype, int mode, const void* logits, uint8_t* out, int B, int H, int W, int K, int Cp, int y0,
                    int x0, int h, int w, ffa_stream_t stream);
 int ffa_onehot_to_index(const float* onehot, uint8_t* idx, int B, int K, int H, int W, ffa_stream_t stream);
+/* counts[target][pred] += 1 (int64, accumulating): the IoU-metric state of tasks_module.py:210-212 */
+int ffa_confusion_matrix(const uint8_t* pred, const uint8_t* target, long long n, int K, long long* counts,
+                         ffa_stream_t stream);
 
 /* ---- host-side tile bookkeeping, bit-exact with the reference's float64 arithmetic
  *      (flair_zonal_detection/slicing.py:51-112, flair_zonal_detection/inference.py:318-335) -------- */

@@ -1,0 +1,59 @@
+"""hipGraph capture of the whole training step: replaying the graph must give what the eager step gives."""
+import pytest
+import torch
+
+from helpers import MOD, TASK, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(graph: bool, steps: int = 4):
+    from flairhip.graph import GraphedTrainStep, make_capturable
+    task, _, cfg = make_pair(precision="bf16", seed=11)
+    task.train()
+    g = torch.Generator().manual_seed(1)
+    batches = [{MOD: torch.randn(2, 5, 64, 64, generator=g).cuda(),
+                TASK: torch.randint(0, 19, (2, 64, 64), generator=g).to(torch.uint8).cuda()} for _ in range(steps)]
+    opt = torch.optim.AdamW(task.model.parameters(), lr=1e-3, weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=steps + 8, pct_start=0.2,
+                                                cycle_momentum=False, div_factor=1000)
+    losses = []
+    if graph:
+        # warm-up steps would move the weights: capture with zero warm-up influence by restoring the state
+        state = {k: v.clone() for k, v in task.state_dict().items()}
+        stepper = GraphedTrainStep(task, opt, batches[0], warmup_steps=2)
+        task.load_state_dict(state)
+        for st in opt.state.values():  # reset the moments the warm-up accumulated
+            for k, v in st.items():
+                if torch.is_tensor(v):
+                    v.zero_()
+        for b in batches:
+            losses.append(stepper(b).item())
+            sched.step()
+    else:
+        # the same optimizer arithmetic as under capture (device-resident fp32 lr and step counter): AdamW's
+        # host-scalar path rounds lr differently, which Adam's normalised update turns into O(lr) weight noise
+        make_capturable(opt)
+        for b in batches:
+            loss = task.training_step(b, 0)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            sched.step()
+            losses.append(loss.item())
+    torch.cuda.synchronize()
+    w = task.model.state_dict()[f"encoders.{MOD}.seg_model.layer2.0.conv1.weight"].float().cpu()
+    confmat = task.train_metrics[TASK].confmat.cpu()
+    nbt = int(task.model.state_dict()[f"encoders.{MOD}.seg_model.bn1.num_batches_tracked"])
+    return losses, w, confmat, nbt
+
+
+def test_graph_replay_matches_eager(cuda):
+    le, we, ce, ne = _run(False)
+    lg, wg, cg, ng = _run(True)
+    # every kernel on the path is deterministic (fixed-order reductions, no float atomics on the training
+    # path), so the replayed trajectory is the eager one bit for bit
+    assert le == lg, (le, lg)
+    assert torch.equal(we, wg), ((we - wg).norm() / we.norm()).item()
+    assert int(cg.sum()) == int(ce.sum()) + 2 * 2 * 64 * 64  # + the two warm-up batches
+    assert ng == ne + 2
