@@ -51,8 +51,8 @@ def _run(graph: bool, steps: int = 4):
 def test_graph_replay_matches_eager(cuda):
     le, we, ce, ne = _run(False)
     lg, wg, cg, ng = _run(True)
-    # every kernel on the path is deterministic (fixed-order reductions, no float atomics on the training
-    # path), so the replayed trajectory is the eager one bit for bit
+    # every kernel on the path is deterministic (fixed-order reductions, no float atomics on the U-Net
+    # path, whose bilinear resize is the identity), so the replayed trajectory is the eager one bit for bit
     assert le == lg, (le, lg)
     assert torch.equal(we, wg), ((we - wg).norm() / we.norm()).item()
     assert int(cg.sum()) == int(ce.sum()) + 2 * 2 * 64 * 64  # + the two warm-up batches
