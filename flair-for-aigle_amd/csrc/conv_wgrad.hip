@@ -637,35 +637,60 @@ __global__ void __launch_bounds__(512, 2) stem_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// dw is OIHW [Co][Ci][taps].  256 threads = SL split lanes x 256/SL quads of four consecutive ci: a lane's
+// slab reads are 16-B loads coalesced along ci, lane l adds splits l, l+SL, ... (four loads in flight, added in
+// index order) and lane 0 then adds the SL lane sums in order -> a fixed summation order for a given
+// (nsplit, SL), and no thread walks hundreds of dependent L2 round trips.  SL = 4 serves the few-slab layers
+// (many channels), SL = 32 the 256-slab ones (few channels).
+template <int SL>
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int nsplit, int CoT, int CiT, int Co,
                     int Ci, int taps, int accumulate) {
-  // dw is OIHW [Co][Ci][taps].  256 threads = 8 split lanes x 32 consecutive (co, tap, ci) outputs: the slab
-  // reads of a lane are coalesced along ci, lane l adds splits l, l+8, ... and lane 0 adds the 8 lane sums in
-  // order -> fixed summation order, and no thread walks hundreds of dependent L2 round trips.
-  __shared__ float sh[8][33];
-  const int ol = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const long long total = (long long)Co * taps * Ci;
-  for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {
-    const long long i = base + ol;
+  constexpr int NQ = 256 / SL;
+  __shared__ float sh[SL][NQ][5];
+  const int ql = threadIdx.x % NQ, sl = threadIdx.x / NQ;
+  const int Cq = (Ci + 3) / 4;
+  const long long total = (long long)Co * taps * Cq;
+  const size_t slab = (size_t)CoT * taps * CiT;
+  for (long long base = (long long)blockIdx.x * NQ; base < total; base += (long long)gridDim.x * NQ) {
+    const long long i = base + ql;
     const bool valid = i < total;
     int ci = 0, tap = 0, co = 0;
-    float s = 0.f;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
     if (valid) {
-      ci = (int)(i % Ci);
-      const long long t2 = i / Ci;
+      ci = (int)(i % Cq) * 4;
+      const long long t2 = i / Cq;
       tap = (int)(t2 % taps);
       co = (int)(t2 / taps);
-      for (int k = sl; k < nsplit; k += 8) s += slabs[(((size_t)k * CoT + co) * taps + tap) * CiT + ci];
+      const float* src = slabs + ((size_t)co * taps + tap) * CiT + ci;
+      for (int k0 = sl; k0 < nsplit; k0 += 4 * SL) {
+        ffa_f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = k0 + u * SL;
+          const ffa_f32x4 t = *reinterpret_cast<const ffa_f32x4*>(src + (size_t)(k < nsplit ? k : k0) * slab);
+          v[u] = k < nsplit ? t : ffa_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[e] += v[u][e];
+      }
     }
-    sh[sl][ol] = s;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sh[sl][ql][e] = s[e];
     __syncthreads();
     if (sl == 0 && valid) {
-      float t = 0.f;
 #pragma unroll
-      for (int l = 0; l < 8; ++l) t += sh[l][ol];
-      float* dst = dw + ((size_t)co * Ci + ci) * taps + tap;
-      *dst = accumulate ? (*dst + t) : t;
+      for (int e = 0; e < 4; ++e) {
+        float t = 0.f;
+#pragma unroll
+        for (int l = 0; l < SL; ++l) t += sh[l][ql][e];
+        if (ci + e < Ci) {
+          float* dst = dw + ((size_t)co * Ci + ci + e) * taps + tap;
+          *dst = accumulate ? (*dst + t) : t;
+        }
+      }
     }
     __syncthreads();
   }
@@ -841,11 +866,18 @@ extern "C" int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* d
   int rc = (dtype == FFA_BF16) ? launch_wgrad<ffa_bf16>(a, p, kh, kw, stride, stream)
                                : launch_wgrad<float>(a, p, kh, kw, stride, stream);
   if (rc != FFA_OK) return rc;
-  const long long total = (long long)Co_real * kh * kw * Ci_real;
-  long long g = (total + 31) / 32;
-  if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)g), dim3(256), 0, stream, (const float*)workspace, dw_oihw,
-                     p.nslab, p.CoT, p.CiT, Co_real, Ci_real, kh * kw, accumulate);
+  const long long total = (long long)Co_real * kh * kw * ((Ci_real + 3) / 4);
+  if (p.nslab > 8) {
+    long long g = (total + 7) / 8;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3((int)g), dim3(256), 0, stream, (const float*)workspace, dw_oihw,
+                       p.nslab, p.CoT, p.CiT, Co_real, Ci_real, kh * kw, accumulate);
+  } else {
+    long long g = (total + 63) / 64;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((int)g), dim3(256), 0, stream, (const float*)workspace, dw_oihw,
+                       p.nslab, p.CoT, p.CiT, Co_real, Ci_real, kh * kw, accumulate);
+  }
   return ffa_check_launch("wgrad_reduce");
 }
 

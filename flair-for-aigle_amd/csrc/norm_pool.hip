@@ -201,9 +201,24 @@ __device__ __forceinline__ bool reduce_partials(const float* __restrict__ ws, in
   c = blockIdx.x * 8 + cl;
   double a = 0.0, b = 0.0;
   if (c < C) {
-    for (int p = lane; p < nparts; p += 32) {
-      a += (double)ws[((long long)p * 2 + 0) * C + c];
-      b += (double)ws[((long long)p * 2 + 1) * C + c];
+    // eight partials' loads in flight per lane, then added in index order: the sum is the same chain of
+    // additions as a plain loop, but costs one memory round trip per eight partials instead of per partial
+    for (int p0 = lane; p0 < nparts; p0 += 32 * 8) {
+      float va[8], vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + 32 * u;
+        const bool ok = p < nparts;
+        const long long o = (long long)(ok ? p : p0) * 2 * C + c;
+        const float ta = ws[o], tb = ws[o + C];
+        va[u] = ok ? ta : 0.f;
+        vb[u] = ok ? tb : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a += (double)va[u];
+        b += (double)vb[u];
+      }
     }
   }
   sh[0][lane][cl] = a;

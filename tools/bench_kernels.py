@@ -56,12 +56,53 @@ def timeit(fn, iters=20, reps=5):
     return best[len(best) // 2]
 
 
+# name, C, H of the BatchNorm layers of the step (count per step in the comment)
+BN_SHAPES = [
+    ("bn_stem", 64, 256),    # 1
+    ("bn_l1", 64, 128),      # 6 (+2 decoder)
+    ("bn_l2", 128, 64),      # 9 (+2)
+    ("bn_l3", 256, 32),      # 13 (+2)
+    ("bn_l4", 512, 16),      # 7
+    ("bn_d3", 32, 256),      # 2
+    ("bn_d4", 16, 512),      # 2
+]
+
+
+def bench_bn(args):
+    dev = torch.device("cuda:0")
+    dt = torch.bfloat16
+    print(f"{'shape':10s} {'kernel':10s} {'us':>9s} {'GB/s':>9s}")
+    for name, C, H in BN_SHAPES:
+        if args.only and args.only != name:
+            continue
+        x = torch.randn(B, H, H, C, device=dev).to(dt)
+        dy = torch.randn(B, H, H, C, device=dev).to(dt)
+        y = torch.empty_like(x)
+        gamma, beta = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        sc, sh, mean, rstd = ops.bn_stats(x, gamma, beta, rm, rv, 0.1, 1e-5)
+        nb = x.numel() * 2
+        runs = [
+            ("stats", lambda: ops.bn_stats(x, gamma, beta, rm, rv, 0.1, 1e-5), nb),
+            ("apply", lambda: ops.bn_apply(x, sc, sh, None, True, out=y), 2 * nb),
+            ("apply+res", lambda: ops.bn_apply(x, sc, sh, dy, True, out=y), 3 * nb),
+            ("bwd(m2)", lambda: ops.bn_bwd(x, dy, None, gamma, beta, mean, rstd, True, False), 5 * nb),
+            ("bwd(m1,dr)", lambda: ops.bn_bwd(x, dy, y, gamma, beta, mean, rstd, True, True), 8 * nb),
+        ]
+        for kname, fn, nbytes in runs:
+            us = timeit(fn, iters=args.iters)
+            print(f"{name:10s} {kname:10s} {us:9.1f} {nbytes / us / 1e3:9.0f}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--bn", action="store_true", help="BatchNorm kernels instead of the convolutions")
     args = ap.parse_args()
+    if args.bn:
+        return bench_bn(args)
     dev = torch.device("cuda:0")
     dt = torch.bfloat16
     kinds = args.kinds.split(",")
