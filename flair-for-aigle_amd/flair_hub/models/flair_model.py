@@ -6,12 +6,15 @@ Same constructor, attributes (``encoders``, ``fusion_handler``, ``main_decoders`
 logits_aux)`` contract.  Inside, tensors are NHWC in the compute dtype (``config['hardware']
 ['precision']``: 'bf16' default, 'fp32' for the 1e-4 parity mode) and every operator is a HIP kernel.
 
-Scope of this round: one mono-temporal modality, one or several tasks.  Multi-modal
-fusion and the Sentinel U-TAE branch raise NotImplementedError naming what is missing.
+Scope (SURVEY.md section 8 + 8f rank 1): any number of mono-temporal modalities (AERIAL_RGBI, AERIAL-RLT_PAN,
+DEM_ELEV, SPOT_RGBI) fused per stage by FusionHandler, one or several tasks, auxiliary per-modality decoders and
+modality dropout.  The Sentinel U-TAE branch raises NotImplementedError naming what is missing.
 """
 from __future__ import annotations
 
 import logging
+import math
+import random
 from typing import Dict, List, Tuple
 
 import torch
@@ -37,9 +40,18 @@ def compute_dtype_of(config: dict) -> torch.dtype:
 
 
 class FusionHandler(nn.Module):
-    """Feature fusion across modalities (reference :437-547).  With a single mono-temporal modality the
-    reference returns that modality's feature list untouched (:489-490) -- the only case wired up so far;
-    the per-stage 1x1 ``conv_f`` parameters are still created so state dicts keep their keys."""
+    """Feature fusion across modalities (reference :437-547).
+
+    One active modality: its feature list is returned untouched (:489-494).  Several mono-temporal modalities
+    (:505-547): every stage of every modality is aligned to the first modality's stage size (bilinear,
+    align_corners=False, only when the sizes differ), the stages are concatenated along channels and mixed by
+    the per-stage 1x1 ``conv_f``.  Here the concat is never materialised: conv_f over the concat is evaluated as
+    a chain of per-modality 1x1 convs through the conv epilogue's residual input (flairhip.nn.fusion_conv1x1).
+
+    Stage 0 (the input-resolution identity feature) is not mixed: every decoder of this build drops it
+    (smp's UnetDecoder.forward starts from ``features[1:]``), so running a 1x1 conv over B x H x W x (C_a + C_b)
+    would be a full-resolution pass nobody reads.  The slot keeps the first modality's tensor; ``conv_f[0]``
+    still exists so state dicts keep their keys."""
 
     def __init__(self, backbones_channels: List[int], target_fused_channels: List[int], mono_keys: List[str],
                  multi_keys: List[str]) -> None:
@@ -50,6 +62,7 @@ class FusionHandler(nn.Module):
             target = target[2:]
         self.conv_f = nn.ModuleList(
             hnn.HipConv2d(cin, cout, 1, 1, 0, bias=True) for cin, cout in zip(backbones_channels, target))
+        self.stage_channels: Dict[str, List[int]] = {}  # real channels per stage of each modality (set by the model)
 
     def forward(self, feature_maps: dict, target_fm_maps):
         active = list(feature_maps.keys())
@@ -59,9 +72,18 @@ class FusionHandler(nn.Module):
             return feature_maps[mono[0]]
         if not mono and len(multi) == 1:
             return feature_maps[multi[0]]
-        raise NotImplementedError(
-            f"feature fusion over modalities {active} is not implemented on libflairhip yet "
-            "(SURVEY.md section 8f rank 1: bilinear align + concat + per-stage 1x1 conv)")
+        if multi:
+            raise NotImplementedError(
+                f"feature fusion with Sentinel time-series branches {multi} is not implemented on libflairhip yet "
+                "(SURVEY.md section 8f rank 3)")
+        nstage = len(target_fm_maps)
+        fused = [target_fm_maps[0]]
+        for s in range(1, nstage):
+            th, tw = target_fm_maps[s].shape[1], target_fm_maps[s].shape[2]
+            xs = [hnn.bilinear(feature_maps[m][s], (th, tw)) for m in active]
+            splits = [self.stage_channels[m][s] for m in active]
+            fused.append(hnn.fusion_conv1x1(xs, splits, self.conv_f[s]))
+        return fused
 
 
 class FLAIR_HUB_Model(nn.Module):
@@ -93,8 +115,9 @@ class FLAIR_HUB_Model(nn.Module):
         if any(inputs.get(k, False) for k in self.multi_keys):
             raise NotImplementedError("Sentinel time-series (U-TAE) branch is not implemented on libflairhip yet "
                                       "(SURVEY.md section 8f rank 3)")
-        if self.aux_losses:
-            raise NotImplementedError("auxiliary decoders are not implemented on libflairhip yet")
+        for m in self.aux_losses:
+            if m not in self.mono_keys:
+                raise NotImplementedError(f"auxiliary decoder for '{m}' needs the U-TAE branch (SURVEY.md 8f rank 3)")
 
         self.encoders = nn.ModuleDict()
         for m in self.mono_keys:
@@ -108,12 +131,19 @@ class FLAIR_HUB_Model(nn.Module):
         total_per_stage = [sum(c) for c in zip(*per_stage)]
         target = next(iter(self.encoders.values())).seg_model.out_channels
         self.fusion_handler = FusionHandler(total_per_stage, target, self.mono_keys, self.multi_keys)
+        self.fusion_handler.stage_channels = {m: list(self.encoders[m].seg_model.out_channels) for m in self.encoders}
 
         self.main_decoders = nn.ModuleDict()
         for task in config["labels"]:
             self.main_decoders[task] = FLAIR_Monotemp(
                 config, channels=1, classes=len(config["labels_configs"][task]["value_name"]), return_type="decoder")
+        # one extra decoder per (aux-loss modality, task), fed by that modality's own features (reference :170-188)
         self.aux_decoders = nn.ModuleDict()
+        for task in config["labels"]:
+            for m in self.aux_losses:
+                self.aux_decoders[f"{m}__{task}"] = FLAIR_Monotemp(
+                    config, channels=1, classes=len(config["labels_configs"][task]["value_name"]),
+                    return_type="decoder")
         self._pack_plan = hnn.PackPlan(self)
         self._log_parameter_table()
 
@@ -122,7 +152,8 @@ class FLAIR_HUB_Model(nn.Module):
     def _log_parameter_table(self) -> None:
         arch = self.config["models"]["monotemp_model"]["arch"]
         total = 0
-        for kind, group in (("backbone", self.encoders), ("task decoder", self.main_decoders)):
+        for kind, group in (("backbone", self.encoders), ("aux loss decoder", self.aux_decoders),
+                            ("task decoder", self.main_decoders)):
             for key, mod in group.items():
                 n = sum(p.numel() for p in mod.parameters())
                 total += n
@@ -144,6 +175,26 @@ class FLAIR_HUB_Model(nn.Module):
             raise RuntimeError("FLAIR_HUB_Model (libflairhip) runs on an MI355X only: move the batch to cuda")
         return hnn.to_nhwc(x, self.compute_dtype, ops.pad_channels(enc.in_channels))
 
+    def modality_dropout(self, feature_maps: Dict[str, list], modalities_dropout_dict: Dict[str, float]):
+        """Reference :328-352: with probability ``modalities_dropout_dict[mod]`` the modality's feature maps are
+        replaced by fresh Xavier-uniform noise (created per call, never trained).  Same host RNG draws
+        (``torch.rand(1)``) as the reference; the noise itself is drawn on the device, so it matches the
+        reference in distribution, not bit for bit.  Xavier bound for an NCHW [B,C,H,W] tensor:
+        fan_in = C*H*W, fan_out = B*H*W (torch.nn.init._calculate_fan_in_and_fan_out)."""
+        for key in feature_maps.keys():
+            if torch.rand(1).item() < modalities_dropout_dict[key]:
+                real = self.fusion_handler.stage_channels[key]
+                noise = []
+                for t, c in zip(feature_maps[key], real):
+                    b, h, w, cp = t.shape
+                    bound = math.sqrt(6.0 / float(c * h * w + b * h * w))
+                    n = torch.empty_like(t).uniform_(-bound, bound)
+                    if cp > c:
+                        n[..., c:] = 0  # pad channels stay zero (layout invariant of every kernel)
+                    noise.append(n)
+                feature_maps[key] = noise
+        return feature_maps
+
     # ---- forward ---------------------------------------------------------------------------------
 
     def forward(self, batch: dict, apply_mod_dropout: bool = False) -> Tuple[Dict[str, torch.Tensor], Dict]:
@@ -161,13 +212,23 @@ class FLAIR_HUB_Model(nn.Module):
         else:
             img_size = tuple(batch[first_mod].shape[-2:])
 
+        logits_tasks: Dict[str, torch.Tensor] = {}
+        logits_aux: Dict[str, torch.Tensor] = {}
+
+        def decode(decoder, feats, task):
+            y = self.interpolate_map(decoder.seg_model(*feats), img_size)
+            return hnn.logits_view(y, len(self.config["labels_configs"][task]["value_name"]))
+
         for mod, encoder in self.encoders.items():
             fmaps[mod] = encoder.seg_model(self._input_nhwc(batch[mod], mod))
-        fused = self.fusion_handler(fmaps, fmaps[first_mod])
+            if self.aux_losses.get(mod):
+                for task in labels:
+                    logits_aux[f"aux_{mod}_{task}"] = decode(self.aux_decoders[f"{mod}__{task}"], fmaps[mod], task)
 
-        logits_tasks: Dict[str, torch.Tensor] = {}
+        if apply_mod_dropout and len(self.encoders) > 1:
+            fmaps = self.modality_dropout(fmaps, {key: random.uniform(0, 1) for key in fmaps.keys()})
+
+        fused = self.fusion_handler(fmaps, fmaps[first_mod])
         for task in labels:
-            y = self.main_decoders[task].seg_model(*fused)
-            y = self.interpolate_map(y, img_size)
-            logits_tasks[task] = hnn.logits_view(y, len(self.config["labels_configs"][task]["value_name"]))
-        return logits_tasks, {}
+            logits_tasks[task] = decode(self.main_decoders[task], fused, task)
+        return logits_tasks, logits_aux

@@ -57,3 +57,31 @@ def unet_resnet34_config(in_channels: int = 5, precision: str = "bf16", batch_si
         "paths": {},
     }
     return cfg
+
+
+LPIS_CLASSES = {
+    0: "grasses", 1: "wheat", 2: "barley", 3: "maize", 4: "other cereals", 5: "rice", 6: "flax/hemp/tobacco",
+    7: "sunflower", 8: "rapeseed", 9: "other oilseed crops", 10: "soy", 11: "other protein crops",
+    12: "fodder legumes", 13: "beetroots", 14: "potatoes", 15: "other arable crops", 16: "vineyard",
+    17: "olive groves", 18: "fruits orchards", 19: "nut orchards", 20: "other permanent crops", 21: "mixed crops",
+    22: "background",
+}
+
+
+def fusion_unet_config(precision: str = "bf16", batch_size: int = 8, aux_loss: bool = True,
+                       lpis_weight: float = 0.5, modality_dropout: float = 0.0) -> dict:
+    """Two mono-temporal modalities (aerial 5 channels + DEM elevation 2 channels) fused per stage, two tasks
+    (COSIA 19 classes, LPIS 23 classes: configs/train/config_supervision.yaml:41-75) and an auxiliary aerial
+    decoder -- the conv part of BASELINE.json's multi-modal configuration."""
+    cfg = unet_resnet34_config(in_channels=5, precision=precision, batch_size=batch_size)
+    cfg["labels"] = ["AERIAL_LABEL-COSIA", "ALL_LABEL-LPIS"]
+    cfg["labels_configs"]["ALL_LABEL-LPIS"] = {
+        "task_weight": lpis_weight, "label_channel_nomenclature": 1, "value_name": deepcopy(LPIS_CLASSES),
+        "value_weights": {"default": 1, "default_exceptions": None, "per_modality_exceptions": {}},
+    }
+    mods = cfg["modalities"]
+    mods["inputs"]["DEM_ELEV"] = True
+    mods["aux_loss"]["AERIAL_RGBI"] = bool(aux_loss)
+    mods["aux_loss_weight"] = {"AERIAL_RGBI": 1.0}
+    mods["modality_dropout"]["DEM_ELEV"] = modality_dropout
+    return cfg

@@ -205,6 +205,52 @@ class _ConvBias(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _FusionConv1x1(torch.autograd.Function):
+    """y = bias + sum_m W[:, slice_m] x_m -- the 1x1 convolution over the channel concat of several sources
+    (FusionHandler.conv_f, flair_hub/models/flair_model.py:470-475,533-541) evaluated WITHOUT the concat: one
+    1x1 conv per source, chained through the conv epilogue's residual input.  Saves a write + a read of the
+    concatenated map per stage and needs no concat kernel in either direction."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, conv: HipConv2d, splits, *xs):
+        out_pitch = ops.pad_channels(conv.out_channels)
+        bpad = None
+        if bias is not None:
+            bpad = torch.zeros(out_pitch, dtype=torch.float32, device=xs[0].device)
+            bpad[: conv.out_channels] = bias.detach()
+        w = weight.detach()
+        y, off = None, 0
+        for m, (x, c) in enumerate(zip(xs, splits)):
+            pw = ops.pack_conv_weight(w[:, off:off + c].contiguous(), x.dtype, 1, x.shape[-1])
+            y = ops.conv2d(x, pw, 0, out_pitch, bias=bpad if m == 0 else None, residual=y)
+            off += c
+        ctx.conv, ctx.splits, ctx.has_bias, ctx.out_pitch = conv, tuple(splits), bias is not None, out_pitch
+        ctx.save_for_backward(weight, *xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight, *xs = ctx.saved_tensors
+        conv, dy = ctx.conv, _as_nhwc_grad(dy)
+        w = weight.detach()
+        dxs, dws, off = [], [], 0
+        for m, (x, c) in enumerate(zip(xs, ctx.splits)):
+            dx = None
+            if ctx.needs_input_grad[4 + m]:
+                pwt = ops.pack_conv_weight(w[:, off:off + c].contiguous(), x.dtype, 1, ctx.out_pitch, transpose=True)
+                dx = ops.conv2d(dy, pwt, 0, x.shape[-1], out_hw=(x.shape[1], x.shape[2]))
+            dxs.append(dx)
+            if ctx.needs_input_grad[0]:
+                dws.append(ops.conv_wgrad(x, dy, conv.out_channels, c, 1, 1, 1, 0))
+            off += c
+        dw = torch.cat(dws, dim=1) if ctx.needs_input_grad[0] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            s, _ = ops.channel_sums(dy)
+            db = s[: conv.out_channels].clone()
+        return (dw, db, None, None, *dxs)
+
+
 class _MaxPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -299,6 +345,15 @@ def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, relu: bool = True, resid
 
 def conv_bias(x, conv: HipConv2d):
     return _ConvBias.apply(x, conv.weight, conv.bias, conv)
+
+
+def fusion_conv1x1(xs, splits, conv: HipConv2d):
+    """conv(cat(xs, channel)) for a 1x1 ``conv`` whose input channels are the sources' real channels in order."""
+    if conv.kernel_size != 1 or conv.stride != 1 or conv.padding != 0:
+        raise ValueError("fusion_conv1x1: expects a 1x1 stride-1 convolution")
+    if sum(splits) != conv.in_channels:
+        raise ValueError(f"fusion_conv1x1: sources carry {sum(splits)} channels, the conv expects {conv.in_channels}")
+    return _FusionConv1x1.apply(conv.weight, conv.bias, conv, tuple(splits), *xs)
 
 
 def max_pool(x):

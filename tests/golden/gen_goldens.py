@@ -14,7 +14,7 @@ small stand-in modules injected into sys.modules for those imports ONLY inside t
 Only data (inputs + the reference's outputs) is written; no reference source is copied.  The fixtures are
 committed; this script is not run on the GPU box (the reference does not travel).
 
-Usage:  python tests/golden/gen_goldens.py
+Usage:  python tests/golden/gen_goldens.py [fusion]
 """
 from __future__ import annotations
 
@@ -278,11 +278,7 @@ def gen_glue(path_json, path_npz):
     from flair_hub.tasks.module_setup import FLAIRLosses, build_segmentation_module
     import flair_zonal_detection.model_utils as ref_mu
     from flair_zonal_detection.inference import initialize_geometry_and_resolutions
-    sys.path.insert(0, os.path.join(ROOT, "flair-for-aigle_amd"))
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("_cfgs", os.path.join(ROOT, "flair-for-aigle_amd", "flairhip", "configs.py"))
-    cfgs = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(cfgs)
+    cfgs = _load_cfgs()
 
     cfg = cfgs.unet_resnet34_config(in_channels=5, precision="fp32")
     cfg["models"]["monotemp_model"]["arch"] = "resnet34-unet"
@@ -333,8 +329,70 @@ def gen_glue(path_json, path_npz):
     print(f"  glue: loss {loss.item():.6f} grad-norm {float(gn):.6f}, {len(info['state_dict_keys'])} state-dict keys")
 
 
+def _load_cfgs():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_cfgs", os.path.join(ROOT, "flair-for-aigle_amd", "flairhip", "configs.py"))
+    cfgs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cfgs)
+    return cfgs
+
+
+FUSION_SAMPLED_GRADS = ["fusion_handler.conv_f.3.weight", "fusion_handler.conv_f.5.bias",
+                        "encoders.DEM_ELEV.seg_model.layer2.0.conv1.weight",
+                        "encoders.AERIAL_RGBI.seg_model.conv1.weight",
+                        "main_decoders.ALL_LABEL-LPIS.seg_model.segmentation_head.0.weight"]
+
+
+def gen_fusion(path_json, path_npz):
+    """Two modalities (aerial 96x96x5 + DEM 64x64x2, so every stage is bilinearly aligned by a factor 1.5; smaller
+    DEM tiles would leave 1x1 pixels x 2 samples for the last BatchNorm's batch statistics, which is numerically
+    meaningless in any implementation), two tasks with task weights 1 / 0.5, an auxiliary aerial decoder: the reference's FLAIR_HUB_Model.forward (FusionHandler
+    case 4) + SegmentationTask.step on CPU, oracle conv stack standing in for smp."""
+    from flair_hub.tasks.module_setup import build_segmentation_module
+    from oracle.seeded_weights import checksum, fill_state_dict
+    cfg = _load_cfgs().fusion_unet_config(precision="fp32")
+    torch.manual_seed(2025)
+    task = build_segmentation_module(cfg, {"AERIAL_RGBI": 96, "DEM_ELEV": 64}, stage="train")
+    task.model.load_state_dict(fill_state_dict(task.model.state_dict()))
+    wsum = checksum(task.model.state_dict())  # before the training step moves the BatchNorm running statistics
+    g = torch.Generator().manual_seed(23)
+    xa = torch.randn(2, 5, 96, 96, generator=g)
+    xd = torch.randn(2, 2, 64, 64, generator=g)
+    tc = torch.randint(0, 19, (2, 96, 96), generator=g)
+    tl = torch.randint(0, 23, (2, 96, 96), generator=g)
+    batch = {"AERIAL_RGBI": xa, "DEM_ELEV": xd,
+             "AERIAL_LABEL-COSIA": torch.nn.functional.one_hot(tc, 19).permute(0, 3, 1, 2).float(),  # one-hot
+             "ALL_LABEL-LPIS": tl}                                                                    # index
+    task.eval()
+    with torch.no_grad():
+        lt, la = task.model(batch)
+    task.train()
+    loss, preds, _ = task.step(batch, training=True)
+    loss.backward()
+    named = dict(task.model.named_parameters())
+    gn = torch.sqrt(sum((p.grad ** 2).sum() for p in named.values() if p.grad is not None))
+    np.savez_compressed(
+        path_npz, x_aerial=xa.numpy(), x_dem=xd.numpy(), t_cosia=tc.numpy().astype(np.uint8),
+        t_lpis=tl.numpy().astype(np.uint8),
+        logits_cosia=lt["AERIAL_LABEL-COSIA"].numpy(), logits_lpis=lt["ALL_LABEL-LPIS"][:1].numpy(),  # sample 0 only
+        logits_aux_cosia=la["aux_AERIAL_RGBI_AERIAL_LABEL-COSIA"][:1].numpy(),                      # (fixture size)
+        preds_train_cosia=preds["AERIAL_LABEL-COSIA"].numpy().astype(np.uint8),
+        preds_train_lpis=preds["ALL_LABEL-LPIS"].numpy().astype(np.uint8),
+        **{"grad__" + k: named[k].grad.numpy() for k in FUSION_SAMPLED_GRADS})
+    info = {"train_loss": hexf(loss.item()), "grad_norm": float(gn), "weights_checksum": wsum,
+            "logit_keys": sorted(lt.keys()), "aux_keys": sorted(la.keys()),
+            "criterion_keys": sorted(task.criterion.keys()),
+            "unused_parameters": sorted(k for k, p in named.items() if p.grad is None),
+            "state_dict_keys": sorted(task.model.state_dict().keys())}
+    json.dump(info, open(path_json, "w"), indent=1)
+    print(f"  fusion: loss {loss.item():.6f} grad-norm {float(gn):.6f}, aux keys {info['aux_keys']}, "
+          f"{len(info['unused_parameters'])} parameters without gradient")
+
+
 def main():
     install_stubs()
+    if sys.argv[1:] == ["fusion"]:  # regenerate only the multi-modality fixture
+        return gen_fusion(os.path.join(HERE, "fusion_two_mod.json"), os.path.join(HERE, "fusion_two_mod.npz"))
     slicing = {}
     gen_slicing(slicing)
     json.dump(slicing, open(os.path.join(HERE, "slicing_grids.json"), "w"))
@@ -343,6 +401,7 @@ def main():
     json.dump(windows, open(os.path.join(HERE, "write_windows.json"), "w"))
     gen_convert(os.path.join(HERE, "convert.npz"))
     gen_glue(os.path.join(HERE, "glue.json"), os.path.join(HERE, "glue_unet64.npz"))
+    gen_fusion(os.path.join(HERE, "fusion_two_mod.json"), os.path.join(HERE, "fusion_two_mod.npz"))
 
 
 if __name__ == "__main__":

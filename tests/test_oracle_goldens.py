@@ -212,6 +212,64 @@ def test_oracle_reproduces_reference_glue_outputs(glue):
     assert (out.argmax(1).numpy().astype(np.uint8) == d["preds_train"]).mean() > 0.9999
 
 
+@pytest.fixture(scope="module")
+def fusion():
+    return json.load(open(os.path.join(GOLD, "fusion_two_mod.json")))
+
+
+def fusion_batch(d, device="cpu"):
+    tc = torch.from_numpy(d["t_cosia"]).long()
+    return {"AERIAL_RGBI": torch.from_numpy(d["x_aerial"]).to(device), "DEM_ELEV": torch.from_numpy(d["x_dem"]).to(device),
+            TASK: torch.nn.functional.one_hot(tc, 19).permute(0, 3, 1, 2).float().to(device),
+            "ALL_LABEL-LPIS": torch.from_numpy(d["t_lpis"]).long().to(device)}
+
+
+def test_fusion_product_surface_matches_reference(fusion):
+    """two modalities + two tasks + an auxiliary decoder: the product builds the modules, criterion keys and
+    state-dict keys the reference builds"""
+    from flairhip.configs import fusion_unet_config
+    from flair_hub.tasks.module_setup import build_segmentation_module
+    task = build_segmentation_module(fusion_unet_config(precision="fp32"), {MOD: 96, "DEM_ELEV": 64}, "train")
+    assert sorted(task.model.state_dict().keys()) == fusion["state_dict_keys"]
+    assert sorted(task.criterion.keys()) == fusion["criterion_keys"]
+    assert sorted(task.model.aux_decoders.keys()) == ["AERIAL_RGBI__AERIAL_LABEL-COSIA", "AERIAL_RGBI__ALL_LABEL-LPIS"]
+
+
+def test_oracle_reproduces_reference_fusion_outputs(fusion):
+    """oracle/fusion_glue.py == the reference's FLAIR_HUB_Model (FusionHandler case 4, aux decoders) and
+    SegmentationTask.step (task-weighted loss sum) run on the same seeded weights and inputs"""
+    from flairhip.configs import fusion_unet_config
+    from oracle.fusion_glue import FlairHubOracle, step_loss
+    from oracle.seeded_weights import checksum, fill_state_dict
+    d = np.load(os.path.join(GOLD, "fusion_two_mod.npz"))
+    oracle = FlairHubOracle(fusion_unet_config(precision="fp32"))
+    assert sorted(oracle.state_dict().keys()) == fusion["state_dict_keys"]
+    oracle.load_state_dict(fill_state_dict(oracle.state_dict()))
+    assert abs(checksum(oracle.state_dict()) - fusion["weights_checksum"]) <= 1e-6 * fusion["weights_checksum"]
+    batch = fusion_batch(d)
+    oracle.eval()
+    with torch.no_grad():
+        lt, la = oracle(batch)
+    assert sorted(lt.keys()) == fusion["logit_keys"] and sorted(la.keys()) == fusion["aux_keys"]
+    scale = np.abs(d["logits_cosia"]).max()
+    assert np.abs(lt[TASK].numpy() - d["logits_cosia"]).max() <= 1e-5 * max(1.0, scale)
+    assert np.abs(lt["ALL_LABEL-LPIS"][:1].numpy() - d["logits_lpis"]).max() <= 1e-5 * max(1.0, np.abs(d["logits_lpis"]).max())
+    assert np.abs(la["aux_AERIAL_RGBI_" + TASK][:1].numpy() - d["logits_aux_cosia"]).max() <= 1e-5 * max(1.0, scale)
+    oracle.train()
+    loss, preds, _ = step_loss(oracle, batch)
+    assert abs(loss.item() - fh(fusion["train_loss"])) <= 1e-5 * fh(fusion["train_loss"])
+    assert (preds[TASK].numpy().astype(np.uint8) == d["preds_train_cosia"]).mean() > 0.9999
+    assert (preds["ALL_LABEL-LPIS"].numpy().astype(np.uint8) == d["preds_train_lpis"]).mean() > 0.9999
+    loss.backward()
+    named = dict(oracle.named_parameters())
+    assert sorted(k for k, p in named.items() if p.grad is None) == fusion["unused_parameters"]
+    gn = torch.sqrt(sum((p.grad ** 2).sum() for p in named.values() if p.grad is not None)).item()
+    assert abs(gn - fusion["grad_norm"]) <= 1e-3 * fusion["grad_norm"]
+    for k in [f[len("grad__"):] for f in d.files if f.startswith("grad__")]:
+        ref = d["grad__" + k]
+        assert np.abs(named[k].grad.numpy() - ref).max() <= 1e-3 * np.abs(ref).max(), k
+
+
 def test_library_exports_every_declared_symbol(lib):
     from flairhip import lib as L
     header = open(os.path.join(ROOT, "include", "flairhip.h")).read()
