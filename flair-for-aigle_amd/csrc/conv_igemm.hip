@@ -22,6 +22,26 @@
 
 #include <stdlib.h>
 
+#ifndef FFA_CONV_READS_FIRST
+#define FFA_CONV_READS_FIRST 0
+#endif
+
+// Developer instrumentation (never built by flairhip/build.py): -DFFA_CONV_TRACE=1 makes wave 0 of the first 64
+// blocks log s_memtime at every phase boundary into a device buffer read back with ffa_conv_trace_read.
+#ifndef FFA_CONV_TRACE
+#define FFA_CONV_TRACE 0
+#endif
+#if FFA_CONV_TRACE
+__device__ long long ffa_conv_trace_buf[64 * 256];
+#define FFA_TRACE(slot_)                                                                    \
+  if (trace_on) {                                                                           \
+    if (trace_n < 256) ffa_conv_trace_buf[blockIdx.x * 256 + trace_n] = (long long)(slot_) << 56 | (__builtin_readcyclecounter() & 0xFFFFFFFFFFFFFFLL); \
+    ++trace_n;                                                                              \
+  }
+#else
+#define FFA_TRACE(slot_)
+#endif
+
 struct ConvArgs {
   const void* in;
   const void* w;
@@ -115,6 +135,11 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
   const int ix_base = ox0 * STRIDE - a.pad;
 
   const int tid = threadIdx.x;
+#if FFA_CONV_TRACE
+  const bool trace_on = (threadIdx.x == 0 && blockIdx.x < 64);
+  int trace_n = 0;
+#endif
+  FFA_TRACE(0)
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wco = wave / WPX;
@@ -181,7 +206,7 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
     const ffa_u32x4* wsrc_ = reinterpret_cast<const ffa_u32x4*>(w_b + (size_t)(c_) * (BCO * G::TAPS * 32)); \
     _Pragma("unroll") for (int k = 0; k < G::NWP; ++k) {                                                     \
       const int i = tid + k * G::NTHR;                                                                       \
-      WR[k] = wsrc_[(G::W_PIECES % G::NTHR == 0 || i < G::W_PIECES) ? i : 0];                                \
+      WR[k] = wsrc_[(k + 1 < G::NWP || G::W_PIECES % G::NTHR == 0 || i < G::W_PIECES) ? i : 0];                                \
     }                                                                                                        \
   }
   /* c_ = chunk whose halo is needed: channel bytes (c_/NRG/HK)*HK*32 .., kernel rows (c_ % NRG)*RG ..
@@ -227,7 +252,7 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
   {                                                                                        \
     _Pragma("unroll") for (int k = 0; k < G::NWP; ++k) {                                   \
       const int i = tid + k * G::NTHR;                                                     \
-      if (G::W_PIECES % G::NTHR == 0 || i < G::W_PIECES) {                                 \
+      if (k + 1 < G::NWP || G::W_PIECES % G::NTHR == 0 || i < G::W_PIECES) {                                 \
         const int row = i / (G::TAPS * 2), col = i % (G::TAPS * 2);                        \
         *reinterpret_cast<ffa_u32x4*>(sW + row * G::WP + col * 16) = WR[k];                \
       }                                                                                    \
@@ -237,13 +262,16 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
   {                                                                                        \
     _Pragma("unroll") for (int k = 0; k < G::NHP; ++k) {                                   \
       const int i = tid + k * G::NTHR;                                                     \
-      if (G::H_PIECES % G::NTHR == 0 || i < G::H_PIECES)                                   \
+      if (k + 1 < G::NHP || G::H_PIECES % G::NTHR == 0 || i < G::H_PIECES)                                   \
         *reinterpret_cast<ffa_u32x4*>(sIn + hlds[k]) = hreg[k];                            \
     }                                                                                      \
   }
 
   // one chunk of matrix work from the LDS images; `sub` = byte offset of the chunk's k-step inside a halo pixel
-  auto compute = [&](int sub) __attribute__((always_inline)) {
+  // `issue(tap)` = the global loads this chunk sends on behalf of later chunks, spread over the taps so that the
+  // texture path (64 B/clk per CU: a block's 29 KB per chunk is ~450 cycles of it) drains under the matrix work
+  // instead of in a burst in front of it; `nv(tap)` = how many VMEM instructions that is (for the pinned order)
+  auto compute = [&](int sub, auto issue, auto nv) __attribute__((always_inline)) {
     // fragments are double-buffered in registers: the ds_reads of tap t+1 are issued before the MFMAs of
     // tap t, so their LDS latency hides under the matrix pipe instead of stalling every tap
     ffa_u32x4 af[2][G::MT], bf[2][G::NT];
@@ -255,6 +283,7 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
     for (int tap = 0; tap < G::TAPS; ++tap) {
       const int cur = tap & 1, nxt = cur ^ 1;
       __builtin_amdgcn_sched_barrier(0);  // one scheduling region per tap: its MFMAs + the reads of the next tap
+      issue(tap);
       if (tap + 1 < G::TAPS) {
         const int r1 = (tap + 1) / KW, s1 = (tap + 1) % KW;
 #pragma unroll
@@ -270,15 +299,23 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
         for (int nt = 0; nt < G::NT; ++nt) Mma<T>::run(af[cur][mt], bf[cur][nt], acc[mt][nt]);
       // pin the interleave (hipcc otherwise sinks the reads back to just before their first use):
       // one MFMA group, one ds_read, ... so every read has a full tap of matrix work to land under
-      if (tap + 1 < G::TAPS) {
-        constexpr int NR = G::MT + G::NT, NM = G::MT * G::NT;
+      {
+        constexpr int NM = G::MT * G::NT;
+        const int NR = (tap + 1 < G::TAPS) ? G::MT + G::NT : 0;
+        const int NV = nv(tap);
         constexpr int PER = (sizeof(T) == 2) ? 1 : 4;  // MFMAs per Mma<T>::run
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
           if (i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (i < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
-        if (NR > NM) __builtin_amdgcn_sched_group_barrier(0x100, NR - NM, 0);
+#pragma unroll
+        for (int i = NM; i < G::MT + G::NT; ++i)
+          if (i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int i = NM; i < NM + 4; ++i)
+          if (i < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -292,24 +329,99 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
     const int cq_ = (c_);                                                                                    \
     if (cq_ + 2 < total_chunks) FFA_LOAD_W(cq_ + 2, WNXT)                                                    \
     if (cq_ + HD < total_chunks && (G::NRG > 1 || ((cq_ + HD) % HK) == 0)) FFA_LOAD_H(cq_ + HD)              \
-    compute((G::NRG > 1) ? 0 : (cq_ % HK) * 32);                                                             \
+    FFA_TRACE(2)                                                                                             \
+    compute((G::NRG > 1) ? 0 : (cq_ % HK) * 32, no_issue, no_nv);                                            \
+    FFA_TRACE(3)                                                                                             \
     __syncthreads();                                                                                         \
+    FFA_TRACE(4)                                                                                             \
     if (cq_ + 1 < total_chunks) {                                                                            \
       FFA_STORE_W(WCUR)                                                                                      \
       if (G::NRG > 1 || ((cq_ + 1) % HK) == 0) FFA_STORE_H()                                                 \
+      FFA_TRACE(5)                                                                                           \
       __syncthreads();                                                                                       \
+      FFA_TRACE(6)                                                                                           \
     }                                                                                                        \
   }
+
+  auto no_issue = [](int) __attribute__((always_inline)) {};
+  auto no_nv = [](int) __attribute__((always_inline)) { return 0; };
 
   FFA_LOAD_W(0, wregA)
   FFA_LOAD_H(0)
   FFA_STORE_W(wregA)
   FFA_STORE_H()
   __syncthreads();
+  FFA_TRACE(1)
   if (total_chunks > 1) FFA_LOAD_W(1, wregA)
-  for (int c = 0; c < total_chunks; c += 2) {
-    FFA_CHUNK(c, wregA, wregB)
-    if (c + 1 < total_chunks) FFA_CHUNK(c + 1, wregB, wregA)
+  if constexpr (HK >= 2 && G::NRG == 1) {
+    // Pipelined path (3x3 stride 1, whole groups of HK chunks per halo fill): every global load is issued from
+    // inside a tap's scheduling region.  Loads are unconditional -- a chunk index past the end is clamped (the
+    // data is never stored), a padding piece reads offset 0 and is zeroed when it is stored -- so the regions hold
+    // no branches and the pinned MFMA / ds_read / global_load order survives.
+    constexpr int HJ = (HK >= 4) ? 1 : 0;  // chunk of the group during which the next group's halo is requested
+    const int last_group = total_chunks - HK;
+    for (int c0 = 0; c0 < total_chunks; c0 += HK) {
+      const int cn = (c0 + HK <= last_group) ? c0 + HK : last_group;  // next group (clamped)
+      const unsigned char* hbase = in_b + (cn / HK) * (HK * 32);
+#pragma unroll
+      for (int j = 0; j < HK; ++j) {
+        const int c = c0 + j;
+        const int cw = (c + 2 < total_chunks) ? c + 2 : total_chunks - 1;
+        const ffa_u32x4* wsrc = reinterpret_cast<const ffa_u32x4*>(w_b + (size_t)cw * (BCO * G::TAPS * 32));
+        auto issue = [&](int tap) __attribute__((always_inline)) {
+#pragma unroll
+          for (int k = 0; k < G::NWP; ++k) {
+            if (k % G::TAPS != tap) continue;
+            const int i = tid + k * G::NTHR;
+            const ffa_u32x4 v = wsrc[(k + 1 < G::NWP || G::W_PIECES % G::NTHR == 0 || i < G::W_PIECES) ? i : 0];
+            if (j & 1) wregA[k] = v;
+            else wregB[k] = v;
+          }
+          if (j == HJ) {
+#pragma unroll
+            for (int k = 0; k < G::NHP; ++k) {
+              if (k % G::TAPS != tap) continue;
+              hreg[k] = *reinterpret_cast<const ffa_u32x4*>(hbase + (unsigned)(hoff[k] >= 0 ? hoff[k] : 0));
+            }
+          }
+        };
+        auto nv = [&](int tap) __attribute__((always_inline)) {
+          int n = 0;
+#pragma unroll
+          for (int k = 0; k < G::NWP; ++k) n += (k % G::TAPS == tap) ? 1 : 0;
+          if (j == HJ) {
+#pragma unroll
+            for (int k = 0; k < G::NHP; ++k) n += (k % G::TAPS == tap) ? 1 : 0;
+          }
+          return n;
+        };
+        FFA_TRACE(2)
+        compute(j * 32, issue, nv);
+        FFA_TRACE(3)
+        __syncthreads();
+        FFA_TRACE(4)
+        if (c + 1 < total_chunks) {
+          if (j & 1) FFA_STORE_W(wregB)
+          else FFA_STORE_W(wregA)
+          if (j == HK - 1) {
+#pragma unroll
+            for (int k = 0; k < G::NHP; ++k) {
+              const int i = tid + k * G::NTHR;
+              if (k + 1 < G::NHP || G::H_PIECES % G::NTHR == 0 || i < G::H_PIECES)
+                *reinterpret_cast<ffa_u32x4*>(sIn + hlds[k]) = (hoff[k] >= 0) ? hreg[k] : ffa_u32x4{0u, 0u, 0u, 0u};
+            }
+          }
+          FFA_TRACE(5)
+          __syncthreads();
+          FFA_TRACE(6)
+        }
+      }
+    }
+  } else {
+    for (int c = 0; c < total_chunks; c += 2) {
+      FFA_CHUNK(c, wregA, wregB)
+      if (c + 1 < total_chunks) FFA_CHUNK(c + 1, wregB, wregA)
+    }
   }
 
 #undef FFA_CHUNK
@@ -384,6 +496,7 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
       }
     }
   }
+  FFA_TRACE(7)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -693,3 +806,15 @@ extern "C" int ffa_pack_conv_weights_batched(int dtype, const void* descs_device
                      static_cast<const PackArgs*>(descs_device), dtype);
   return ffa_check_launch("pack_weight_batched");
 }
+
+#if FFA_CONV_TRACE
+extern "C" int ffa_conv_trace_read(long long* host_dst, int n) {
+  if (n > 64 * 256) n = 64 * 256;
+  hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ffa_conv_trace_buf), (size_t)n * sizeof(long long));
+}
+extern "C" int ffa_conv_trace_clear() {
+  static long long zeros[64 * 256];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(ffa_conv_trace_buf), zeros, sizeof(zeros));
+}
+#endif
