@@ -17,6 +17,24 @@
 
 #include <stdlib.h>
 
+// Developer instrumentation (never built by flairhip/build.py): -DFFA_WGRAD_TRACE=1 makes wave 0 of the first 64
+// blocks log s_memtime at every phase boundary (tools/conv_trace.py).
+#ifndef FFA_WGRAD_TRACE
+#define FFA_WGRAD_TRACE 0
+#endif
+#if FFA_WGRAD_TRACE
+__device__ long long ffa_wgrad_trace_buf[64 * 256];
+#define FFA_WTRACE(slot_)                                                                   \
+  if (trace_on) {                                                                           \
+    if (trace_n < 256)                                                                      \
+      ffa_wgrad_trace_buf[(blockIdx.y * gridDim.x + blockIdx.x) * 256 + trace_n] =          \
+          (long long)(slot_) << 56 | (__builtin_readcyclecounter() & 0xFFFFFFFFFFFFFFLL);    \
+    ++trace_n;                                                                              \
+  }
+#else
+#define FFA_WTRACE(slot_)
+#endif
+
 struct WgradArgs {
   const void* x;
   const void* dy;
@@ -78,6 +96,11 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
   unsigned char* sIn = smem + G::DY_BYTES;
 
   const int tid = threadIdx.x;
+#if FFA_WGRAD_TRACE
+  const bool trace_on = (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 64);
+  int trace_n = 0;
+#endif
+  FFA_WTRACE(0)
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wk = wave / (WCO * WCI);
@@ -112,7 +135,39 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
   ffa_u32x4 dreg[G::NDP];
   ffa_u32x4 ireg[G::NIP];
 
-#define FFA_WG_LOAD(pt_)                                                                                       \
+  // Tile-independent piece geometry, computed once: byte offset relative to the tile origin (-1: the piece never
+  // exists -- past the piece count or in a pad channel block) and its (row, column) inside the tile / halo, packed
+  // as row << 8 | column.  Per tile only the origin (scalar) and the bounds tests remain: the per-piece index
+  // arithmetic (divisions, 64-bit multiplies, ~250 cycles per piece) used to keep all eight waves out of the
+  // matrix pipe for a quarter of every tile (tools/conv_trace.py).
+  constexpr bool PRE = (EB == 2 && KH == 3 && STRIDE == 1);  // elsewhere the piece tables would spill
+  int drel[PRE ? G::NDP : 1], irel[PRE ? G::NIP : 1];
+  unsigned short dpos[PRE ? G::NDP : 1], ipos[PRE ? G::NIP : 1];
+#pragma unroll
+  for (int k = 0; k < (PRE ? G::NDP : 0); ++k) {
+    const int i = tid + k * G::NTHR;
+    const int part = i % G::PARTS;
+    const int n = (i / G::PARTS) % G::NPX;
+    const int plane = i / (G::PARTS * G::NPX);
+    const int c = co0 + plane * 32 + part * (16 / EB);
+    const int r = n / TW, col = n % TW;
+    dpos[k] = (unsigned short)((r << 8) | col);
+    drel[k] = (i < G::DY_PIECES && c < a.Co) ? ((r * a.Wo + col) * a.Co + c) * EB : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < (PRE ? G::NIP : 0); ++k) {
+    const int i = tid + k * G::NTHR;
+    const int part = i % G::PARTS;
+    const int q = (i / G::PARTS) % (G::IH * G::IW);
+    const int plane = i / (G::PARTS * G::IH * G::IW);
+    const int c = ci0 + plane * 32 + part * (16 / EB);
+    const int r = (q / G::IW) * G::GSTEP, col = (q % G::IW) * G::GSTEP;
+    ipos[k] = (unsigned short)((r << 8) | col);
+    irel[k] = (i < G::IN_PIECES && c < a.Ci) ? ((r * a.Wi + col) * a.Ci + c) * EB : -1;
+  }
+  static_assert(!PRE || (G::IH * G::GSTEP < 256 && G::IW * G::GSTEP < 256), "packed piece position");
+
+#define FFA_WG_LOAD_GENERIC(pt_)                                                                                       \
   {                                                                                                            \
     const int tx_ = (pt_) % a.tiles_x;                                                                         \
     const int t2_ = (pt_) / a.tiles_x;                                                                         \
@@ -149,6 +204,32 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
       ireg[k] = v;                                                                                             \
     }                                                                                                          \
   }
+
+#define FFA_WG_LOAD(pt_)                                                                                       \
+  if constexpr (!PRE) FFA_WG_LOAD_GENERIC(pt_) else {                                                          \
+    const int tx_ = (pt_) % a.tiles_x;                                                                         \
+    const int t2_ = (pt_) / a.tiles_x;                                                                         \
+    const int ty_ = t2_ % a.tiles_y;                                                                           \
+    const int b_ = t2_ / a.tiles_y;                                                                            \
+    const int oy0_ = ty_ * TH, ox0_ = tx_ * TW;                                                                \
+    const int iy0_ = oy0_ * STRIDE - a.pad + rg * RG;                                                          \
+    const int ix0_ = ox0_ * STRIDE - a.pad;                                                                    \
+    const unsigned char* dyt_ = dy_b + ((long long)(b_ * a.Ho + oy0_) * a.Wo + ox0_) * (long long)(a.Co * EB); \
+    const unsigned char* xt_ = x_b + ((long long)(b_ * a.Hi + iy0_) * a.Wi + ix0_) * (long long)(a.Ci * EB);   \
+    _Pragma("unroll") for (int k = 0; k < G::NDP; ++k) {                                                       \
+      ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};                                                                 \
+      if (drel[k] >= 0 && oy0_ + (dpos[k] >> 8) < a.Ho && ox0_ + (dpos[k] & 0xff) < a.Wo)                      \
+        v = *reinterpret_cast<const ffa_u32x4*>(dyt_ + (unsigned)drel[k]);                                     \
+      dreg[k] = v;                                                                                             \
+    }                                                                                                          \
+    _Pragma("unroll") for (int k = 0; k < G::NIP; ++k) {                                                       \
+      ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};                                                                 \
+      if (irel[k] >= 0 && (unsigned)(iy0_ + (ipos[k] >> 8)) < (unsigned)a.Hi &&                                \
+          (unsigned)(ix0_ + (ipos[k] & 0xff)) < (unsigned)a.Wi)                                                \
+        v = *reinterpret_cast<const ffa_u32x4*>(xt_ + (unsigned)irel[k]);                                      \
+      ireg[k] = v;                                                                                             \
+    }                                                                                                          \
+  }
 #define FFA_WG_STORE()                                                                          \
   {                                                                                             \
     _Pragma("unroll") for (int k = 0; k < G::NDP; ++k) {                                        \
@@ -165,11 +246,16 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
 
   int pt = split;
   if (pt < a.npt) FFA_WG_LOAD(pt)
+  FFA_WTRACE(1)
   for (; pt < a.npt; pt += a.nsplit) {
     __syncthreads();  // previous tile's fragment reads are done
+    FFA_WTRACE(2)
     FFA_WG_STORE()    // piece i lives at byte i*16: [plane][pixel][32 ch] is linear in the piece index
+    FFA_WTRACE(3)
     __syncthreads();
+    FFA_WTRACE(4)
     if (pt + a.nsplit < a.npt) FFA_WG_LOAD(pt + a.nsplit)
+    FFA_WTRACE(5)
 
     // ---- K loop over the tile's pixels, 16 per step; wave wk takes steps wk, wk + WK, ...
 #pragma unroll 1
@@ -235,8 +321,10 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
         }
       }
     }
+    FFA_WTRACE(6)
   }
 #undef FFA_WG_LOAD
+#undef FFA_WG_LOAD_GENERIC
 #undef FFA_WG_STORE
 
   // ---- sum the k-split wave groups through LDS (fixed order: group 0 + group 1 + ...)
@@ -277,6 +365,7 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
       a.slabs[((slab * a.CoT + co) * taps_total + tapg) * a.CiT + ci] = acc[t][r];
     }
   }
+  FFA_WTRACE(7)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -940,3 +1029,15 @@ extern "C" int ffa_probe_mfma(const float* A, const float* B, float* D, int use_
   hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, stream, A, B, D, use_f32);
   return ffa_check_launch("probe_mfma");
 }
+
+#if FFA_WGRAD_TRACE
+extern "C" int ffa_wgrad_trace_read(long long* host_dst, int n) {
+  if (n > 64 * 256) n = 64 * 256;
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(ffa_wgrad_trace_buf), (size_t)n * sizeof(long long));
+}
+extern "C" int ffa_wgrad_trace_clear() {
+  static long long zeros[64 * 256];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(ffa_wgrad_trace_buf), zeros, sizeof(zeros));
+}
+#endif

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflairhip.so")
+# FLAIRHIP_LIB selects another build of the same library (kernel A/B runs); there is still no fallback
+LIB_PATH = os.environ.get("FLAIRHIP_LIB") or os.path.join(_HERE, "libflairhip.so")
 
 BF16 = 0
 F32 = 1

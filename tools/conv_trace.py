@@ -28,10 +28,13 @@ def build_trace_lib() -> str:
     out_dir = os.path.join(B.CSRC, "build")
     obj = os.path.join(out_dir, "conv_igemm_trace.o")
     so = os.path.join(out_dir, "libflairhip_trace.so")
-    flags = [f"--offload-arch={B.ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-DFFA_CONV_TRACE=1"]
+    flags = [f"--offload-arch={B.ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-DFFA_CONV_TRACE=1",
+             "-DFFA_WGRAD_TRACE=1"]
+    obj2 = os.path.join(out_dir, "conv_wgrad_trace.o")
     subprocess.run([B._hipcc()] + flags + ["-c", os.path.join(B.CSRC, "conv_igemm.hip"), "-o", obj], check=True)
+    subprocess.run([B._hipcc()] + flags + ["-c", os.path.join(B.CSRC, "conv_wgrad.hip"), "-o", obj2], check=True)
     objs = [os.path.join(out_dir, os.path.splitext(s)[0] + ".o") for s in B.HIP_SOURCES + B.CXX_SOURCES
-            if s != "conv_igemm.hip"] + [obj]
+            if s not in ("conv_igemm.hip", "conv_wgrad.hip")] + [obj, obj2]
     subprocess.run([B._hipcc(), "-shared", "-fPIC", f"--offload-arch={B.ARCH}", "-o", so] + objs, check=True)
     return so
 
@@ -51,7 +54,6 @@ def main():
     from flairhip import ops
     import bench_kernels as BK
     lib = L.load()
-    lib.ffa_conv_trace_read.argtypes = [C.c_void_p, C.c_int]
     name, cin, cout, k, stride, pad, H = next(s for s in BK.CONV_SHAPES if s[0] == shape)
     dev, dt, B = torch.device("cuda:0"), torch.bfloat16, BK.B
     cip, cop = ops.pad_channels(cin), ops.pad_channels(cout)
@@ -59,7 +61,14 @@ def main():
     x = torch.randn(B, H, H, cip, device=dev).to(dt)
     w = torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5
     dy = torch.randn(B, Ho, Ho, cop, device=dev).to(dt)
-    if kind == "fwd":
+    read, clear = lib.ffa_conv_trace_read, lib.ffa_conv_trace_clear
+    names = {1: "prologue", 2: "issue", 3: "compute", 4: "bar1", 5: "store", 6: "bar2", 7: "epilogue"}
+    if kind == "wgrad":
+        dw = torch.empty(cout, cin, k, k, device=dev)
+        run = lambda: ops.conv_wgrad(x, dy, cout, cin, k, k, stride, pad, out=dw)
+        read, clear = lib.ffa_wgrad_trace_read, lib.ffa_wgrad_trace_clear
+        names = {1: "prologue", 2: "bar1", 3: "store", 4: "bar2", 5: "issue", 6: "compute", 7: "epilogue"}
+    elif kind == "fwd":
         pw = ops.pack_conv_weight(w, dt, stride, cip)
         run = lambda: ops.conv2d(x, pw, pad, cop)
     else:
@@ -68,12 +77,12 @@ def main():
     for _ in range(3):
         run()
     torch.cuda.synchronize()
-    lib.ffa_conv_trace_clear()
+    clear()
     run()
     torch.cuda.synchronize()
     buf = (C.c_longlong * (64 * 256))()
-    lib.ffa_conv_trace_read(buf, 64 * 256)
-    names = {1: "prologue", 2: "issue", 3: "compute", 4: "bar1", 5: "store", 6: "bar2", 7: "epilogue"}
+    read.argtypes = [C.c_void_p, C.c_int]
+    read(buf, 64 * 256)
     totals, blocks, spans = {}, 0, []
     for b in range(64):
         ev = [(v >> 56, v & ((1 << 56) - 1)) for v in buf[b * 256:(b + 1) * 256] if v]
