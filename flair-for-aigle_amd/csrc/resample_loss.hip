@@ -421,6 +421,35 @@ extern "C" int ffa_softmax_ce(int dtype, const void* logits, const uint8_t* targ
   return ffa_check_launch("softmax_ce");
 }
 
+// x *= scale[0] (device scalar), skipped entirely when the scalar is exactly 1: the loss forward already wrote
+// dlogits for an upstream gradient of 1, which is what loss.backward() supplies unless the caller scales the
+// loss -- the usual step then costs one 4-byte read per block instead of a second pass over the logits.
+template <typename T>
+__global__ void scale_inplace_kernel(T* __restrict__ x, long long nvec, const float* __restrict__ scale) {
+  const float s = scale[0];
+  if (s == 1.f) return;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec;
+       i += (long long)gridDim.x * blockDim.x) {
+    float v[8];
+    ffa_load8<T>(x + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= s;
+    ffa_store8<T>(x + i * 8, v);
+  }
+}
+
+extern "C" int ffa_scale_inplace(int dtype, void* x, long long n, const float* scale, hipStream_t stream) {
+  FFA_REQUIRE(x && scale && n % 8 == 0, "scale_inplace: bad arguments");
+  const long long nvec = n / 8;
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(scale_inplace_kernel<ffa_bf16>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
+                       (ffa_bf16*)x, nvec, scale);
+  else
+    hipLaunchKernelGGL(scale_inplace_kernel<float>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream, (float*)x,
+                       nvec, scale);
+  return ffa_check_launch("scale_inplace");
+}
+
 // ------------------------------------------------------------------------------------------------
 // prediction conversion for the zonal tile loop
 

@@ -303,25 +303,29 @@ class _ToNHWC(torch.autograd.Function):
 
 
 class _SoftmaxCE(torch.autograd.Function):
-    """Weighted-mean CE over NHWC logits; backward recomputes the softmax and scales by grad_output
-    read on the device (no host sync)."""
+    """Weighted-mean CE over NHWC logits.  When the logits need a gradient the forward pass writes dlogits too
+    (for an upstream gradient of 1, in the same pass over the logits); backward multiplies them by the actual
+    grad_output read on the device -- a no-op kernel when it is exactly 1 (plain ``loss.backward()``) -- so the
+    usual training step reads the logits once instead of twice and never synchronises with the host."""
 
     @staticmethod
     def forward(ctx, logits, targets, weights, num_classes, holder):
-        loss, wsum, _, pred = ops.softmax_ce(logits, targets, weights, num_classes, want_grad=False, want_pred=True)
+        need = ctx.needs_input_grad[0]
+        loss, wsum, dlogits, pred = ops.softmax_ce(logits, targets, weights, num_classes, want_grad=need,
+                                                   want_pred=True)
         if holder is not None:
             holder["pred"] = pred
             holder["wsum"] = wsum
-        ctx.save_for_backward(logits, targets, weights)
-        ctx.k = num_classes
+        ctx.dlogits = dlogits
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        logits, targets, weights = ctx.saved_tensors
+        dlogits, ctx.dlogits = ctx.dlogits, None
+        if dlogits is None:
+            raise RuntimeError("softmax-CE backward called twice (the fused gradient buffer was already consumed)")
         gs = g.detach().reshape(1).float().contiguous()
-        _, _, dlogits, _ = ops.softmax_ce(logits, targets, weights, ctx.k, grad_scale=gs, want_grad=True)
-        return dlogits, None, None, None, None
+        return ops.scale_inplace(dlogits, gs), None, None, None, None
 
 
 def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, relu: bool = True, residual=None):

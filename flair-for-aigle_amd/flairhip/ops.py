@@ -371,6 +371,15 @@ def softmax_ce(logits: torch.Tensor, targets: torch.Tensor, class_weights: torch
     return res[0:1], res[1:2], dlogits, pred
 
 
+def scale_inplace(x: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """x *= scale[0] (device f32 scalar) in place; the kernel returns at once when the scalar is exactly 1."""
+    lib = _l.load()
+    if not x.is_contiguous() or x.numel() % 8:
+        raise ValueError("scale_inplace: contiguous tensor with a multiple of 8 elements expected")
+    _l.check(lib.ffa_scale_inplace(_dt(x), x.data_ptr(), x.numel(), scale.data_ptr(), _stream()), "scale_inplace")
+    return x
+
+
 def predict_u8(logits: torch.Tensor, num_classes: int, mode: str = "argmax", crop: Optional[Tuple[int, int, int, int]] = None
                ) -> torch.Tensor:
     """NHWC logits -> uint8 prediction of the cropped window (y0, x0, h, w).

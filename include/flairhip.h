@@ -112,6 +112,11 @@ long long ffa_softmax_ce_workspace_bytes(void);
 int ffa_softmax_ce(int dtype, const void* logits, const uint8_t* targets, const float* class_weights,
                    const float* grad_scale, float* loss, float* wsum_out, void* dlogits, uint8_t* pred,
                    long long npix, int K, int Cp, void* workspace, long long workspace_bytes, ffa_stream_t stream);
+
+/* x[0..n) *= scale[0] in place, scale a device scalar; a no-op pass when the scalar is exactly 1.  Used on the
+ * dlogits ffa_softmax_ce wrote in the forward pass (for an upstream gradient of 1) when autograd hands the loss a
+ * different grad_output -- replaces the second softmax pass torch.autograd would make (tasks_module.py:155). */
+int ffa_scale_inplace(int dtype, void* x, long long n, const float* scale, ffa_stream_t stream);
 int ffa_predict_u8(int dtype, int mode, const void* logits, uint8_t* out, int B, int H, int W, int K, int Cp, int y0,
                    int x0, int h, int w, ffa_stream_t stream);
 int ffa_onehot_to_index(const float* onehot, uint8_t* idx, int B, int K, int H, int W, ffa_stream_t stream);

@@ -390,3 +390,25 @@ def test_onehot_to_index(cuda):
     idx = ops.onehot_to_index(oh.to(cuda))
     torch.cuda.synchronize()
     assert torch.equal(idx.cpu().long(), t)
+
+
+@pytest.mark.parametrize("scale", [1.0, 0.25])
+def test_loss_backward_reuses_forward_gradient(cuda, scale):
+    """HipCrossEntropyLoss writes dlogits in the forward pass; backward rescales them by the upstream gradient
+    read on the device (exactly 1 -> untouched)."""
+    from flairhip import nn as hnn
+    g = torch.Generator().manual_seed(4)
+    B, K, H, W = 2, 19, 24, 32
+    z = torch.randn(B, K, H, W, generator=g) * 2
+    t = torch.randint(0, K, (B, H, W), generator=g)
+    wts = torch.tensor([1.0] * 15 + [0.0] * 4)
+    zr = z.clone().requires_grad_(True)
+    (F.cross_entropy(zr, t, weight=wts) * scale).backward()
+    zn = to_nhwc(z, torch.float32, cuda, hnn.LOGIT_PITCH).requires_grad_(True)
+    crit = hnn.HipCrossEntropyLoss(weight=wts, num_classes=K).to(cuda)
+    loss = crit(hnn.logits_view(zn, K), t.to(torch.uint8).to(cuda))
+    (loss * scale).backward()
+    torch.cuda.synchronize()
+    assert (from_nhwc(zn.grad, K) - zr.grad).abs().max().item() <= 1e-7
+    with torch.no_grad():  # no gradient wanted: the forward pass must not allocate one
+        crit(hnn.logits_view(zn.detach(), K), t.to(torch.uint8).to(cuda))
