@@ -170,6 +170,69 @@ class _ConvBnAct(torch.autograd.Function):
         return dx, dw, dgamma, dbeta, dres, None, None, None
 
 
+class _BasicBlock(torch.autograd.Function):
+    """One ResNet BasicBlock in training mode as a single autograd node:
+        y = relu( bn2(conv2( relu(bn1(conv1(x))) )) + identity ),   identity = x  or  bn_d(conv_d(x)).
+    Same kernels as the layer-wise path; what the fusion buys is the backward of the fork at x: the gradient of
+    the identity branch enters the last dgrad convolution through its epilogue's residual input instead of being
+    summed by a separate elementwise pass over the block's input (16 such passes per step in ResNet-34)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, blk):
+        c1, n1, c2, n2 = blk.conv1, blk.bn1, blk.conv2, blk.bn2
+        down = blk.downsample is not None
+        x1 = ops.conv2d(x, c1.packed(x.dtype), c1.padding, c1.out_pitch)
+        sc1, sh1, m1, r1 = ops.bn_stats(x1, g1, b1, n1.running_mean, n1.running_var, n1.momentum, n1.eps)
+        n1.note_batch()
+        y1 = ops.bn_apply(x1, sc1, sh1, relu=True)
+        if down:
+            cd, nd = blk.downsample[0], blk.downsample[1]
+            xd = ops.conv2d(x, cd.packed(x.dtype), cd.padding, cd.out_pitch)
+            scd, shd, md, rd = ops.bn_stats(xd, gd, bd, nd.running_mean, nd.running_var, nd.momentum, nd.eps)
+            nd.note_batch()
+            idt = ops.bn_apply(xd, scd, shd, relu=False)
+        else:
+            xd = md = rd = None
+            idt = x
+        x2 = ops.conv2d(y1, c2.packed(x.dtype), c2.padding, c2.out_pitch)
+        sc2, sh2, m2, r2 = ops.bn_stats(x2, g2, b2, n2.running_mean, n2.running_var, n2.momentum, n2.eps)
+        n2.note_batch()
+        y = ops.bn_apply(x2, sc2, sh2, residual=idt, relu=True)
+        ctx.blk = blk
+        ctx.save_for_backward(x, x1, y1, x2, y, xd, g1, b1, m1, r1, g2, b2, m2, r2, gd, bd, md, rd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x1, y1, x2, y, xd, g1, b1, m1, r1, g2, b2, m2, r2, gd, bd, md, rd = ctx.saved_tensors
+        blk = ctx.blk
+        c1, c2 = blk.conv1, blk.conv2
+        dy = _as_nhwc_grad(dy)
+
+        def dgrad(conv, d, like, residual=None):
+            k = conv.kernel_size
+            return ops.conv2d(d, conv.packed(d.dtype, transpose=True), k - 1 - conv.padding, like.shape[-1],
+                              dil=conv.stride, out_hw=(like.shape[1], like.shape[2]), residual=residual)
+
+        def wgrad(conv, inp, d):
+            return ops.conv_wgrad(inp, d, conv.out_channels, conv.in_channels, conv.kernel_size, conv.kernel_size,
+                                  conv.stride, conv.padding)
+
+        d2, dres, dg2, db2 = ops.bn_bwd(x2, dy, y, g2, b2, m2, r2, True, True)
+        dw2 = wgrad(c2, y1, d2) if ctx.needs_input_grad[4] else None
+        dy1 = dgrad(c2, d2, y1)
+        d1, _, dg1, db1 = ops.bn_bwd(x1, dy1, None, g1, b1, m1, r1, True, False)
+        dw1 = wgrad(c1, x, d1) if ctx.needs_input_grad[1] else None
+        dwd = dgd = dbd = None
+        if blk.downsample is not None:
+            cd = blk.downsample[0]
+            dd, _, dgd, dbd = ops.bn_bwd(xd, dres, None, gd, bd, md, rd, False, False)
+            dwd = wgrad(cd, x, dd) if ctx.needs_input_grad[7] else None
+            dres = dgrad(cd, dd, x) if ctx.needs_input_grad[0] else None
+        dx = dgrad(c1, d1, x, residual=dres) if ctx.needs_input_grad[0] else None
+        return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None
+
+
 class _ConvBias(torch.autograd.Function):
     """y = conv(x) + bias  (segmentation head; output pitch LOGIT_PITCH, pad channels zero)"""
 
@@ -345,6 +408,17 @@ def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, relu: bool = True, resid
         hit = (ver, pw, shift)
         conv._cache["eval_fold"] = hit
     return ops.conv2d(x, hit[1], conv.padding, conv.out_pitch, bias=hit[2], residual=residual, relu=relu)
+
+
+def basic_block(x, blk):
+    """Training-mode forward of a BasicBlock module (conv1, bn1, conv2, bn2, downsample) as one autograd node."""
+    if blk.downsample is not None:
+        cd, nd = blk.downsample[0], blk.downsample[1]
+        extra = (cd.weight, nd.weight, nd.bias)
+    else:
+        extra = (None, None, None)
+    return _BasicBlock.apply(x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight,
+                             blk.bn2.bias, *extra, blk)
 
 
 def conv_bias(x, conv: HipConv2d):
