@@ -108,8 +108,11 @@ extern "C" int ffa_upsample_nearest2x_concat_fwd(int dtype, const void* lo, cons
 
 extern "C" int ffa_upsample_nearest2x_concat_bwd(int dtype, const void* dcat, void* dlo, void* dskip, int B, int Hl,
                                                  int Wl, int C1, int C2, hipStream_t stream) {
-  FFA_REQUIRE(dcat && dlo && C1 % 8 == 0 && C2 % 8 == 0 && (C2 == 0 || dskip), "up2_concat_bwd: bad arguments");
-  const long long items = (long long)B * Hl * Wl * (C1 / 8) + (long long)B * Hl * 2 * Wl * 2 * (C2 / 8);
+  // dskip may be null with C2 > 0: the caller then uses the channel slice dcat[..., C1:] itself as the skip gradient
+  // (it is only ever summed with the encoder-side gradient of the same feature map, which reads strided input fine)
+  FFA_REQUIRE(dcat && dlo && C1 % 8 == 0 && C2 % 8 == 0, "up2_concat_bwd: bad arguments");
+  const long long items =
+      (long long)B * Hl * Wl * (C1 / 8) + (dskip ? (long long)B * Hl * 2 * Wl * 2 * (C2 / 8) : 0LL);
   if (dtype == FFA_BF16)
     hipLaunchKernelGGL(up2_concat_bwd_kernel<ffa_bf16>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
                        (const ffa_bf16*)dcat, (ffa_bf16*)dlo, (ffa_bf16*)(C2 ? dskip : nullptr), B, Hl, Wl, C1, C2);

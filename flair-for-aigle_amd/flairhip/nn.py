@@ -336,7 +336,10 @@ class _UpConcat(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dcat):
-        dlo, dskip = ops.upsample2x_concat_bwd(_as_nhwc_grad(dcat), ctx.c1)
+        # every skip feature of the U-Net also feeds the next encoder stage, so its gradient is summed with another
+        # one right away: hand autograd the channel slice of dcat instead of a copy (consumers that need a
+        # contiguous tensor make one themselves, _as_nhwc_grad)
+        dlo, dskip = ops.upsample2x_concat_bwd(_as_nhwc_grad(dcat), ctx.c1, skip_as_view=True)
         return dlo, dskip
 
 

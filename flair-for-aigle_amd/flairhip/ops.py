@@ -306,15 +306,19 @@ def upsample2x_concat_fwd(lo: torch.Tensor, skip: Optional[torch.Tensor]) -> tor
     return out
 
 
-def upsample2x_concat_bwd(dcat: torch.Tensor, c1: int):
+def upsample2x_concat_bwd(dcat: torch.Tensor, c1: int, skip_as_view: bool = False):
+    """-> (dlo, dskip).  With ``skip_as_view`` the skip gradient is the channel slice of ``dcat`` itself (no copy):
+    fine for a consumer that reads strided input, e.g. the sum with the encoder-side gradient of the same map."""
     lib = _l.load()
     _chk_nhwc(dcat, "upsample grad")
     B, H, W, C_ = dcat.shape
     c2 = C_ - c1
     dlo = torch.empty((B, H // 2, W // 2, c1), dtype=dcat.dtype, device=dcat.device)
-    dskip = torch.empty((B, H, W, c2), dtype=dcat.dtype, device=dcat.device) if c2 else None
+    dskip = torch.empty((B, H, W, c2), dtype=dcat.dtype, device=dcat.device) if (c2 and not skip_as_view) else None
     _l.check(lib.ffa_upsample_nearest2x_concat_bwd(_dt(dcat), dcat.data_ptr(), dlo.data_ptr(), _ptr(dskip), B, H // 2,
                                                    W // 2, c1, c2, _stream()), "upsample2x_concat_bwd")
+    if c2 and skip_as_view:
+        dskip = dcat[..., c1:]
     return dlo, dskip
 
 

@@ -97,6 +97,7 @@ int ffa_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H
 /* ---- decoder resampling (smp DecoderBlock nearest x2 + cat; flair_model.py:318-327 interpolate_map) */
 int ffa_upsample_nearest2x_concat_fwd(int dtype, const void* lo, const void* skip, void* out, int B, int Hl, int Wl,
                                       int C1, int C2, ffa_stream_t stream);
+/* dskip may be null: only dlo (2x2 sums of the first C1 channels) is written and the caller uses dcat[..., C1:] */
 int ffa_upsample_nearest2x_concat_bwd(int dtype, const void* dcat, void* dlo, void* dskip, int B, int Hl, int Wl,
                                       int C1, int C2, ffa_stream_t stream);
 int ffa_bilinear_fwd(int dtype, const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C,
