@@ -47,6 +47,7 @@ struct ConvArgs {
   const void* w;
   void* out;
   const float* bias;  // [>= co block coverage] or null
+  float* stats;       // [npt][2][Co] per-tile channel sums / sums of squares of the stored output, or null
   const void* res;    // same layout as out, or null
   int B, Hi, Wi, Ci;  // stored input dims (Ci = channel pitch)
   int Ho, Wo, Co;     // Co = stored output channel pitch
@@ -435,6 +436,13 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
   T* out = static_cast<T*>(a.out);
   const T* res = static_cast<const T*>(a.res);
   const int co_wave = cb * BCO + wco * G::WAVE_CO;
+  // BatchNorm batch statistics of the tensor being written, from the registers that hold it (a.stats != null):
+  // per lane NCH channels x (sum, sum of squares) over its pixels, of the values AS STORED (bf16-rounded)
+  constexpr int NCH = (G::MT == 2) ? 32 : 16;
+  float st[2 * NCH];
+  const bool want_stats = a.stats != nullptr;
+#pragma unroll
+  for (int i = 0; i < 2 * NCH; ++i) st[i] = 0.f;
 #pragma unroll
   for (int nt = 0; nt < G::NT; ++nt) {
     const int n = wpx * G::WAVE_PX + nt * 32 + rho;
@@ -467,6 +475,14 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
           for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
         }
         ffa_store8<T>(out + pix + c0, v);
+        if (want_stats) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float r = (EB == 2) ? ffa_bf16_bits_to_f32(ffa_f32_to_bf16_bits(v[i])) : v[i];
+            st[g * 8 + i] += r;
+            st[NCH + g * 8 + i] += r * r;
+          }
+        }
       } else {
         const int c0 = co_wave + 8 * g + 4 * half;
         if (c0 >= a.Co) continue;
@@ -493,7 +509,67 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
         } else {
           *reinterpret_cast<float4*>(out + pix + c0) = make_float4(v[0], v[1], v[2], v[3]);
         }
+        if (want_stats) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float r = (EB == 2) ? ffa_bf16_bits_to_f32(ffa_f32_to_bf16_bits(v[i])) : v[i];
+            st[g * 4 + i] += r;
+            st[NCH + g * 4 + i] += r * r;
+          }
+        }
       }
+    }
+  }
+  if (want_stats) {
+    static_assert(WCO == 1, "the statistics epilogue assumes one co wave group per block");
+    // Transposing reduction over the 32 lanes of a half-wave: at every step a lane keeps one half of its values and
+    // adds the partner's copy of that half -- 2*NCH - 2 shuffles instead of 5 per value.  Afterwards lane rho holds
+    // two entries of [sums | sums of squares]: entry index = (bits of rho, high to low) * 2 + j.
+#pragma unroll
+    for (int bit = 4; bit >= 0; --bit) {
+      const int n = (2 * NCH) >> (4 - bit);  // values a lane still holds (compile-time: the loop is unrolled)
+      if (n > 2) {
+        const bool up = (rho >> bit) & 1;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+          if (j < n / 2) {
+            // (the two reads go through an opaque asm: hipcc otherwise rewrites "up ? st[a] : st[b]" into
+            // st[up ? a : b], a dynamically indexed register array = a 32-way compare/select chain per value)
+            float lo = st[j], hi = st[j + n / 2];
+            asm volatile("" : "+v"(lo), "+v"(hi));
+            const float keep = up ? hi : lo;
+            const float send = up ? lo : hi;
+            st[j] = keep + __shfl_xor(send, 1 << bit, 64);
+          }
+        }
+      } else {  // NCH == 16: the last lane bit is a plain butterfly, both lanes of a pair end up with the totals
+        st[0] += __shfl_xor(st[0], 1 << bit, 64);
+        st[1] += __shfl_xor(st[1], 1 << bit, 64);
+      }
+    }
+    // the pixel waves of the block add up through LDS (free: a barrier followed the last fragment reads)
+    float* red = reinterpret_cast<float*>(smem);
+    red[(wpx * 64 + lane) * 2 + 0] = st[0];
+    red[(wpx * 64 + lane) * 2 + 1] = st[1];
+    __syncthreads();
+    constexpr int NOUT = (G::MT == 2) ? 128 : 64;
+    if (tid < NOUT) {
+      const int j = tid & 1;
+      const int ln = (G::MT == 2) ? (tid >> 1) : ((tid >> 1) * 2);  // MT == 1: even lanes carry the totals
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WPX; ++w) t += red[(w * 64 + ln) * 2 + j];
+      const int r5 = ln & 31, hf = ln >> 5;
+      const int which = r5 >> 4;
+      int c;
+      if (G::MT == 2) {
+        const int L = (r5 & 15) * 2 + j;
+        c = cb * BCO + 16 * (L >> 3) + 8 * hf + (L & 7);
+      } else {
+        const int L = ((r5 >> 1) & 7) * 2 + j;
+        c = cb * BCO + 8 * (L >> 2) + 4 * hf + (L & 3);
+      }
+      if (c < a.Co) a.stats[((size_t)pt * 2 + which) * a.Co + c] = t;
     }
   }
   FFA_TRACE(7)
@@ -578,9 +654,10 @@ extern "C" int ffa_conv_block_co(int kh, int kw, int stride, int cout) {
 
 extern "C" int ffa_conv_row_group(int kh) { return conv_rg(kh); }
 
-extern "C" int ffa_conv2d(int dtype, const void* in, const void* w_packed, const float* bias, const void* residual,
-                          void* out, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int co_rows, int bco,
-                          int kh, int kw, int stride, int pad, int dil, int relu, hipStream_t stream) {
+static int conv2d_impl(int dtype, const void* in, const void* w_packed, const float* bias, const void* residual,
+                       void* out, float* stat_partials, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
+                       int co_rows, int bco, int kh, int kw, int stride, int pad, int dil, int relu,
+                       hipStream_t stream) {
   FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "conv: bad dtype %d", dtype);
   FFA_REQUIRE(in && w_packed && out, "conv: null pointer");
   FFA_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "conv: bad dims");
@@ -604,6 +681,7 @@ extern "C" int ffa_conv2d(int dtype, const void* in, const void* w_packed, const
   a.w = w_packed;
   a.out = out;
   a.bias = bias;
+  a.stats = stat_partials;
   a.res = residual;
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci;
   a.Ho = Ho; a.Wo = Wo; a.Co = Co;
@@ -616,6 +694,31 @@ extern "C" int ffa_conv2d(int dtype, const void* in, const void* w_packed, const
   a.ncb = co_rows / p.bco;
   if (dtype == FFA_BF16) return launch_dtype<ffa_bf16>(a, kh, kw, stride, p, stream);
   return launch_dtype<float>(a, kh, kw, stride, p, stream);
+}
+
+extern "C" int ffa_conv2d(int dtype, const void* in, const void* w_packed, const float* bias, const void* residual,
+                          void* out, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int co_rows, int bco,
+                          int kh, int kw, int stride, int pad, int dil, int relu, hipStream_t stream) {
+  return conv2d_impl(dtype, in, w_packed, bias, residual, out, nullptr, B, Hi, Wi, Ci, Ho, Wo, Co, co_rows, bco, kh, kw,
+                     stride, pad, dil, relu, stream);
+}
+
+// Number of partial-statistics rows ffa_conv2d_stats writes for an output of B x Ho x Wo pixels (= pixel tiles).
+extern "C" long long ffa_conv_stat_rows(int B, int Ho, int Wo) {
+  const int tw = (Wo >= 32) ? 32 : 16, th = (Wo >= 32) ? 8 : 16;
+  return (long long)B * ffa_cdiv(Wo, tw) * ffa_cdiv(Ho, th);
+}
+
+// ffa_conv2d that also leaves per-tile channel sums / sums of squares of the tensor it writes in
+// stat_partials[rows][2][Co] (rows = ffa_conv_stat_rows): the BatchNorm batch statistics come out of the conv
+// epilogue's registers instead of a second pass over the output (ffa_bn_finalize turns them into scale / shift).
+extern "C" int ffa_conv2d_stats(int dtype, const void* in, const void* w_packed, const float* bias,
+                                const void* residual, void* out, float* stat_partials, int B, int Hi, int Wi, int Ci,
+                                int Ho, int Wo, int Co, int co_rows, int bco, int kh, int kw, int stride, int pad,
+                                int dil, int relu, hipStream_t stream) {
+  FFA_REQUIRE(stat_partials, "conv_stats: null statistics buffer");
+  return conv2d_impl(dtype, in, w_packed, bias, residual, out, stat_partials, B, Hi, Wi, Ci, Ho, Wo, Co, co_rows, bco,
+                     kh, kw, stride, pad, dil, relu, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

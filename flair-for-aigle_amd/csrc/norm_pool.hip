@@ -288,6 +288,75 @@ extern "C" int ffa_bn_stats(int dtype, const void* x, long long npix, int C, con
   return ffa_check_launch("bn_stats");
 }
 
+// Folds many partial rows ws[p][2][C] (p < nparts) into R rows dst[r][2][C]: row r is the fixed-order sum of the
+// partials p = r, r + R, ...  (the conv epilogue leaves one partial per pixel tile: up to 32768 of them)
+__global__ void __launch_bounds__(FFA_FIN_THREADS)
+partials_fold_kernel(const float* __restrict__ ws, long long nparts, int C, int R, float* __restrict__ dst) {
+  const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;  // 32 lanes x 8 channels
+  const int c = blockIdx.x * 8 + cl;
+  const int r = blockIdx.y;
+  __shared__ float sh[2][32][8];
+  float a = 0.f, b = 0.f;
+  if (c < C) {
+    for (long long p0 = r + (long long)lane * R; p0 < nparts; p0 += 32LL * 4 * R) {
+      float va[4], vb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long p = p0 + 32LL * u * R;
+        const bool ok = p < nparts;
+        const long long o = (ok ? p : p0) * 2 * C + c;
+        const float ta = ws[o], tb = ws[o + C];
+        va[u] = ok ? ta : 0.f;
+        vb[u] = ok ? tb : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a += va[u];
+        b += vb[u];
+      }
+    }
+  }
+  sh[0][lane][cl] = a;
+  sh[1][lane][cl] = b;
+  __syncthreads();
+  if (lane == 0 && c < C) {
+    float s = 0.f, q = 0.f;
+    for (int l = 0; l < 32; ++l) {
+      s += sh[0][l][cl];
+      q += sh[1][l][cl];
+    }
+    dst[((long long)r * 2 + 0) * C + c] = s;
+    dst[((long long)r * 2 + 1) * C + c] = q;
+  }
+}
+
+// Training-mode BatchNorm parameters from partial sums somebody else produced (ffa_conv2d_stats): same outputs and
+// running-statistics update as ffa_bn_stats, without the pass over the tensor.
+extern "C" int ffa_bn_finalize(const float* partials, long long nparts, long long npix, int C, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               float* scale, float* shift, float* mean_out, float* rstd_out, void* workspace,
+                               long long workspace_bytes, hipStream_t stream) {
+  FFA_REQUIRE(partials && scale && shift && mean_out && rstd_out && workspace, "bn_finalize: null pointer");
+  FFA_REQUIRE(C % 8 == 0 && C >= 8 && nparts > 0 && npix > 0, "bn_finalize: bad arguments");
+  if (workspace_bytes < ffa_bn_workspace_bytes(C)) {
+    ffa_set_error("bn_finalize: workspace too small");
+    return FFA_ERR_WORKSPACE;
+  }
+  const float* src = partials;
+  int n = (int)nparts;
+  if (nparts > FFA_MAX_PARTIALS) {
+    const int R = 64;
+    float* ws = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(partials_fold_kernel, dim3(ffa_cdiv(C, 8), R), dim3(FFA_FIN_THREADS), 0, stream, partials, nparts,
+                       C, R, ws);
+    src = ws;
+    n = R;
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ffa_cdiv(C, 8)), dim3(FFA_FIN_THREADS), 0, stream, src, n, (double)npix,
+                     C, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, rstd_out);
+  return ffa_check_launch("bn_finalize");
+}
+
 __global__ void bn_eval_params_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ running_mean, const float* __restrict__ running_var,
                                       float eps, float* __restrict__ scale, float* __restrict__ shift) {

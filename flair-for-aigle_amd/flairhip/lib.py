@@ -49,10 +49,13 @@ SIGNATURES = {
     "ffa_pack_desc_fill": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "ffa_pack_conv_weights_batched": (_i, [_i, _p, _i, _p]),
     "ffa_conv2d": (_i, [_i, _p, _p, _p, _p, _p] + [_i] * 15 + [_p]),
+    "ffa_conv_stat_rows": (_ll, [_i, _i, _i]),
+    "ffa_conv2d_stats": (_i, [_i, _p, _p, _p, _p, _p, _p] + [_i] * 15 + [_p]),
     "ffa_conv_wgrad_workspace_bytes": (_ll, [_i] * 9),
     "ffa_conv_wgrad": (_i, [_i, _p, _p, _p] + [_i] * 14 + [_p, _ll, _p]),
     "ffa_bn_workspace_bytes": (_ll, [_i]),
     "ffa_bn_stats": (_i, [_i, _p, _ll, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _ll, _p]),
+    "ffa_bn_finalize": (_i, [_p, _ll, _ll, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _ll, _p]),
     "ffa_bn_eval_params": (_i, [_i, _p, _p, _p, _p, _f, _p, _p, _p]),
     "ffa_bn_apply": (_i, [_i, _p, _p, _p, _p, _p, _ll, _i, _i, _p]),
     "ffa_bn_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p, _ll, _p]),

@@ -140,8 +140,8 @@ class _ConvBnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, conv: HipConv2d, bn: HipBatchNorm2d, relu: bool):
         pw = conv.packed(x.dtype)
-        y0 = ops.conv2d(x, pw, conv.padding, conv.out_pitch)
-        scale, shift, mean, rstd = ops.bn_stats(y0, gamma, beta, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+        y0, scale, shift, mean, rstd = ops.conv2d_bn_stats(x, pw, conv.padding, conv.out_pitch, gamma, beta,
+                                                          bn.running_mean, bn.running_var, bn.momentum, bn.eps)
         bn.note_batch()
         y = ops.bn_apply(y0, scale, shift, residual=residual, relu=relu)
         ctx.conv, ctx.relu, ctx.has_res = conv, relu, residual is not None
@@ -181,21 +181,21 @@ class _BasicBlock(torch.autograd.Function):
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, blk):
         c1, n1, c2, n2 = blk.conv1, blk.bn1, blk.conv2, blk.bn2
         down = blk.downsample is not None
-        x1 = ops.conv2d(x, c1.packed(x.dtype), c1.padding, c1.out_pitch)
-        sc1, sh1, m1, r1 = ops.bn_stats(x1, g1, b1, n1.running_mean, n1.running_var, n1.momentum, n1.eps)
+        x1, sc1, sh1, m1, r1 = ops.conv2d_bn_stats(x, c1.packed(x.dtype), c1.padding, c1.out_pitch, g1, b1,
+                                                   n1.running_mean, n1.running_var, n1.momentum, n1.eps)
         n1.note_batch()
         y1 = ops.bn_apply(x1, sc1, sh1, relu=True)
         if down:
             cd, nd = blk.downsample[0], blk.downsample[1]
-            xd = ops.conv2d(x, cd.packed(x.dtype), cd.padding, cd.out_pitch)
-            scd, shd, md, rd = ops.bn_stats(xd, gd, bd, nd.running_mean, nd.running_var, nd.momentum, nd.eps)
+            xd, scd, shd, md, rd = ops.conv2d_bn_stats(x, cd.packed(x.dtype), cd.padding, cd.out_pitch, gd, bd,
+                                                       nd.running_mean, nd.running_var, nd.momentum, nd.eps)
             nd.note_batch()
             idt = ops.bn_apply(xd, scd, shd, relu=False)
         else:
             xd = md = rd = None
             idt = x
-        x2 = ops.conv2d(y1, c2.packed(x.dtype), c2.padding, c2.out_pitch)
-        sc2, sh2, m2, r2 = ops.bn_stats(x2, g2, b2, n2.running_mean, n2.running_var, n2.momentum, n2.eps)
+        x2, sc2, sh2, m2, r2 = ops.conv2d_bn_stats(y1, c2.packed(x.dtype), c2.padding, c2.out_pitch, g2, b2,
+                                                   n2.running_mean, n2.running_var, n2.momentum, n2.eps)
         n2.note_batch()
         y = ops.bn_apply(x2, sc2, sh2, residual=idt, relu=True)
         ctx.blk = blk

@@ -6,6 +6,8 @@ every function launches on ``torch.cuda.current_stream()`` and returns immediate
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -132,8 +134,11 @@ def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:
 
 def conv2d(x: torch.Tensor, w: PackedWeight, pad: int, out_channels: int, bias: Optional[torch.Tensor] = None,
            residual: Optional[torch.Tensor] = None, relu: bool = False, dil: int = 1,
-           out_hw: Optional[Tuple[int, int]] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[B,Ho,Wo,out_channels] = relu?(conv(x, w) + bias + residual).  out_channels is the stored pitch."""
+           out_hw: Optional[Tuple[int, int]] = None, out: Optional[torch.Tensor] = None,
+           stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[B,Ho,Wo,out_channels] = relu?(conv(x, w) + bias + residual).  out_channels is the stored pitch.
+    ``stats`` (f32, >= conv_stat_rows * 2 * out_channels elements) receives per-tile channel sums / sums of squares
+    of the stored output for a following training-mode BatchNorm (see bn_finalize)."""
     lib = _l.load()
     _chk_nhwc(x, "conv input")
     B, Hi, Wi, Ci = x.shape
@@ -149,10 +154,48 @@ def conv2d(x: torch.Tensor, w: PackedWeight, pad: int, out_channels: int, bias: 
         raise ValueError("conv2d: residual shape mismatch")
     if bias is not None and bias.numel() < out_channels:
         raise ValueError("conv2d: bias shorter than the output pitch")
+    if stats is not None:
+        if stats.dtype != torch.float32 or stats.numel() < conv_stat_rows(B, Ho, Wo) * 2 * out_channels:
+            raise ValueError("conv2d: statistics buffer too small or not f32")
+        _l.check(lib.ffa_conv2d_stats(_dt(x), x.data_ptr(), w.data.data_ptr(), _ptr(bias), _ptr(residual),
+                                      out.data_ptr(), stats.data_ptr(), B, Hi, Wi, Ci, Ho, Wo, out_channels, w.rows,
+                                      w.bco, w.kh, w.kw, w.stride, pad, dil, 1 if relu else 0, _stream()),
+                 "conv2d_stats")
+        return out
     _l.check(lib.ffa_conv2d(_dt(x), x.data_ptr(), w.data.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
                             B, Hi, Wi, Ci, Ho, Wo, out_channels, w.rows, w.bco, w.kh, w.kw, w.stride, pad, dil,
                             1 if relu else 0, _stream()), "conv2d")
     return out
+
+
+FUSED_BN_STATS = os.environ.get("FFA_FUSED_BN_STATS", "1") != "0"
+
+
+def conv_stat_rows(B: int, Ho: int, Wo: int) -> int:
+    return int(_l.load().ffa_conv_stat_rows(B, Ho, Wo))
+
+
+def conv2d_bn_stats(x: torch.Tensor, w: PackedWeight, pad: int, out_channels: int, gamma, beta, running_mean,
+                    running_var, momentum: float, eps: float):
+    """conv + the batch statistics of its output in one kernel: -> (y0, scale, shift, mean, rstd); the running
+    buffers are updated in place.  Equivalent to conv2d followed by bn_stats, minus one pass over y0."""
+    lib = _l.load()
+    if not FUSED_BN_STATS:  # A/B switch (FFA_FUSED_BN_STATS=0): the two-kernel path
+        y0 = conv2d(x, w, pad, out_channels)
+        return (y0,) + tuple(bn_stats(y0, gamma, beta, running_mean, running_var, momentum, eps))
+    B, Hi, Wi, _ = x.shape
+    Ho, Wo = conv_out_size(Hi, w.kh, w.stride, pad), conv_out_size(Wi, w.kw, w.stride, pad)
+    rows = conv_stat_rows(B, Ho, Wo)
+    dev = x.device
+    part = workspace(rows * 2 * out_channels * 4, dev, "bnpart").view(torch.float32)
+    y0 = conv2d(x, w, pad, out_channels, stats=part)
+    out = torch.empty((4, out_channels), dtype=torch.float32, device=dev)
+    ws = workspace(lib.ffa_bn_workspace_bytes(out_channels), dev, "bn")
+    _l.check(lib.ffa_bn_finalize(part.data_ptr(), rows, B * Ho * Wo, out_channels, _ptr(gamma), _ptr(beta),
+                                 _ptr(running_mean), _ptr(running_var), momentum, eps, out[0].data_ptr(),
+                                 out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), ws.data_ptr(), ws.numel(),
+                                 _stream()), "bn_finalize")
+    return y0, out[0], out[1], out[2], out[3]
 
 
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, co_real: int, ci_real: int, kh: int, kw: int, stride: int,

@@ -63,6 +63,16 @@ int ffa_pack_conv_weights_batched(int dtype, const void* descs_device, int n, ff
 int ffa_conv2d(int dtype, const void* in, const void* w_packed, const float* bias, const void* residual, void* out,
                int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int co_rows, int bco, int kh, int kw, int stride,
                int pad, int dil, int relu, ffa_stream_t stream);
+
+/* ffa_conv2d that also writes, per pixel tile, the channel sums and sums of squares of the output it stores:
+ * stat_partials[rows][2][Co] f32, rows = ffa_conv_stat_rows(B, Ho, Wo).  With ffa_bn_finalize this replaces the
+ * separate statistics pass of a training-mode BatchNorm that follows the convolution (torch.nn.functional.batch_norm
+ * as called by smp's Conv2dReLU / torchvision's BasicBlock). */
+long long ffa_conv_stat_rows(int B, int Ho, int Wo);
+int ffa_conv2d_stats(int dtype, const void* in, const void* w_packed, const float* bias, const void* residual,
+                     void* out, float* stat_partials, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
+                     int co_rows, int bco, int kh, int kw, int stride, int pad, int dil, int relu,
+                     ffa_stream_t stream);
 long long ffa_conv_wgrad_workspace_bytes(int dtype, int kh, int kw, int stride, int Co, int Ci, int B, int Ho, int Wo);
 int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int B, int Hi, int Wi, int Ci, int Ho,
                    int Wo, int Co, int Co_real, int Ci_real, int kh, int kw, int stride, int pad, int accumulate,
@@ -74,6 +84,11 @@ long long ffa_bn_workspace_bytes(int C);
 int ffa_bn_stats(int dtype, const void* x, long long npix, int C, const float* gamma, const float* beta,
                  float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                  float* mean_out, float* rstd_out, void* workspace, long long workspace_bytes, ffa_stream_t stream);
+/* ffa_bn_stats without the pass over the tensor: partials[nparts][2][C] come from ffa_conv2d_stats */
+int ffa_bn_finalize(const float* partials, long long nparts, long long npix, int C, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                    float* scale, float* shift, float* mean_out, float* rstd_out, void* workspace,
+                    long long workspace_bytes, ffa_stream_t stream);
 int ffa_bn_eval_params(int C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, ffa_stream_t stream);
 int ffa_bn_apply(int dtype, const void* x, const void* residual, void* y, const float* scale, const float* shift,

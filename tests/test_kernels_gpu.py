@@ -412,3 +412,40 @@ def test_loss_backward_reuses_forward_gradient(cuda, scale):
     assert (from_nhwc(zn.grad, K) - zr.grad).abs().max().item() <= 1e-7
     with torch.no_grad():  # no gradient wanted: the forward pass must not allocate one
         crit(hnn.logits_view(zn.detach(), K), t.to(torch.uint8).to(cuda))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("cin,cout,k,stride,H,W", [
+    (64, 64, 3, 1, 40, 72),     # 64-row blocks, ragged tiles (8x32 tiles over 40x72)
+    (32, 16, 3, 1, 24, 40),     # 32-row blocks (4-channel runs per lane), pad channels in the block
+    (128, 256, 3, 2, 32, 32),   # stride 2, 16x16 tiles
+    (5, 64, 7, 2, 64, 96),      # stem
+    (64, 128, 1, 2, 32, 64),    # 1x1 downsample
+    (16, 32, 3, 1, 300, 48),    # > 1024 pixel tiles: two-level fold of the partials
+])
+def test_conv_epilogue_statistics_match_separate_pass(cuda, dtype, cin, cout, k, stride, H, W):
+    """ffa_conv2d_stats + ffa_bn_finalize == ffa_conv2d followed by ffa_bn_stats (scale, shift, mean, rstd and the
+    running buffers), on the values as stored"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    B = 9 if H * W > 10000 else 3
+    pad = k // 2
+    cip, cop = ops.pad_channels(cin), ops.pad_channels(cout)
+    x = to_nhwc(torch.randn(B, cin, H, W, generator=g), dtype, cuda, cip)
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(cuda)
+    gamma = (torch.rand(cop, generator=g) + 0.5).to(cuda)
+    beta = torch.randn(cop, generator=g).to(cuda)
+    pw = ops.pack_conv_weight(w, dtype, stride, cip)
+    rm1, rv1 = torch.zeros(cop, device=cuda), torch.ones(cop, device=cuda)
+    rm2, rv2 = torch.zeros(cop, device=cuda), torch.ones(cop, device=cuda)
+    y_ref = ops.conv2d(x, pw, pad, cop)
+    ref = ops.bn_stats(y_ref, gamma, beta, rm1, rv1, 0.1, 1e-5)
+    y, *got = ops.conv2d_bn_stats(x, pw, pad, cop, gamma, beta, rm2, rv2, 0.1, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    if B * y.shape[1] * y.shape[2] > 1024 * 256:
+        assert ops.conv_stat_rows(B, y.shape[1], y.shape[2]) > 1024
+    for name, a_, b_ in zip(("scale", "shift", "mean", "rstd"), got, ref):
+        assert torch.allclose(a_[:cout], b_[:cout], rtol=2e-5, atol=2e-6), name
+    assert torch.allclose(rm2[:cout], rm1[:cout], rtol=2e-5, atol=2e-7)
+    assert torch.allclose(rv2[:cout], rv1[:cout], rtol=2e-5, atol=2e-7)

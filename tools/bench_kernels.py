@@ -125,8 +125,10 @@ def main():
         out = torch.empty(B, Ho, Ho, cop, device=dev, dtype=dt)
         dx = torch.empty(B, H, H, cip, device=dev, dtype=dt)
         dw = torch.empty(cout, cin, k, k, device=dev)
+        stats = torch.empty(ops.conv_stat_rows(B, Ho, Ho) * 2 * cop, device=dev)
         runs = {
             "fwd": lambda: ops.conv2d(x, pw, pad, cop, out=out),
+            "fwdst": lambda: ops.conv2d(x, pw, pad, cop, out=out, stats=stats),  # + BatchNorm statistics epilogue
             "dgrad": lambda: ops.conv2d(dy, pwt, k - 1 - pad, cip, dil=stride, out_hw=(H, H), out=dx),
             "wgrad": lambda: ops.conv_wgrad(x, dy, cout, cin, k, k, stride, pad, out=dw),
         }
