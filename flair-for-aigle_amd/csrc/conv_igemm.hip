@@ -48,6 +48,8 @@ struct ConvArgs {
   void* out;
   const float* bias;  // [>= co block coverage] or null
   float* stats;       // [npt][2][Co] per-tile channel sums / sums of squares of the stored output, or null
+  const void* in2;    // UP kernels: the skip tensor [B][Hi][Wi][C2]; `in` is then the low-res map [B][Hi/2][Wi/2][C1]
+  int c1_bytes;       // UP kernels: bytes of one pixel of `in` (C1 * sizeof(T)); the virtual input has Ci = C1 + C2
   const void* res;    // same layout as out, or null
   int B, Hi, Wi, Ci;  // stored input dims (Ci = channel pitch)
   int Ho, Wo, Co;     // Co = stored output channel pitch
@@ -111,8 +113,13 @@ struct ConvGeom {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <typename T, int KH, int KW, int STRIDE, int RG, int BCO, int WCO, int WPX, int TH, int TW, int HK>
+// UP = the input is the VIRTUAL tensor cat(nearest_x2(in), in2) of a U-Net decoder block (smp DecoderBlock:
+// F.interpolate(scale_factor=2, mode="nearest") + torch.cat): channel groups below C1 are fetched from the low-res
+// map at (y/2, x/2), the rest from the skip tensor, so the concatenated tensor is never written or re-read.
+template <typename T, int KH, int KW, int STRIDE, int RG, int BCO, int WCO, int WPX, int TH, int TW, int HK,
+          bool UP = false>
 __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs a) {
+  static_assert(!UP || (HK >= 2 && KH == 3 && STRIDE == 1), "the two-source loader lives in the pipelined 3x3 path");
   using G = ConvGeom<KH, KW, STRIDE, RG, BCO, WCO, WPX, TH, TW, HK>;
   constexpr int EB = ElemTraits<T>::kBytes;
   __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
@@ -184,6 +191,7 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
   // halo piece geometry, computed once: byte offset from the input base (32-bit: the host checks the tensor is
   // smaller than 2 GiB), -1 where the piece is padding / zero insertion / past the tile; LDS byte address
   int hoff[G::NHP], hlds[G::NHP];
+  int hoff2[UP ? G::NHP : 1];  // UP: offsets into the skip tensor (hoff then addresses the low-res map)
 #pragma unroll
   for (int k = 0; k < G::NHP; ++k) {
     const int i = tid + k * G::NTHR;
@@ -198,7 +206,12 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
       vx >>= 1;
     }
     ok = ok && vy < a.Hi && vx < a.Wi;
-    hoff[k] = ok ? (((b * a.Hi + vy) * a.Wi + vx) * a.Ci * EB + hh * 16) : -1;
+    if constexpr (UP) {
+      hoff[k] = ok ? (((b * (a.Hi >> 1) + (vy >> 1)) * (a.Wi >> 1) + (vx >> 1)) * a.c1_bytes + hh * 16) : -1;
+      hoff2[k] = ok ? (((b * a.Hi + vy) * a.Wi + vx) * (a.Ci * EB - a.c1_bytes) + hh * 16) : -1;
+    } else {
+      hoff[k] = ok ? (((b * a.Hi + vy) * a.Wi + vx) * a.Ci * EB + hh * 16) : -1;
+    }
     hlds[k] = q * G::PP + hh * 16;
   }
 
@@ -363,7 +376,9 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
     const int last_group = total_chunks - HK;
     for (int c0 = 0; c0 < total_chunks; c0 += HK) {
       const int cn = (c0 + HK <= last_group) ? c0 + HK : last_group;  // next group (clamped)
-      const unsigned char* hbase = in_b + (cn / HK) * (HK * 32);
+      const int gbn = (cn / HK) * (HK * 32);  // its first channel byte within a (virtual) input pixel
+      const bool nextA = !UP || gbn < a.c1_bytes;
+      const unsigned char* hbase = nextA ? in_b + gbn : static_cast<const unsigned char*>(a.in2) + (gbn - a.c1_bytes);
 #pragma unroll
       for (int j = 0; j < HK; ++j) {
         const int c = c0 + j;
@@ -382,7 +397,9 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
 #pragma unroll
             for (int k = 0; k < G::NHP; ++k) {
               if (k % G::TAPS != tap) continue;
-              hreg[k] = *reinterpret_cast<const ffa_u32x4*>(hbase + (unsigned)(hoff[k] >= 0 ? hoff[k] : 0));
+              int off = hoff[k];
+              if constexpr (UP) off = nextA ? hoff[k] : hoff2[k];
+              hreg[k] = *reinterpret_cast<const ffa_u32x4*>(hbase + (unsigned)(off >= 0 ? off : 0));
             }
           }
         };
@@ -601,12 +618,21 @@ static bool conv_supported(int kh, int kw, int stride, int bco) {
   return bco == 64 || bco == 32;
 }
 
-template <typename T, int KH, int KW, int STRIDE, int RG, int BCO, int WCO, int WPX, int TH, int TW, int HK>
+template <typename T, int KH, int KW, int STRIDE, int RG, int BCO, int WCO, int WPX, int TH, int TW, int HK,
+          bool UP = false>
 static int launch_hk(const ConvArgs& a, hipStream_t stream) {
   const int grid = ffa_cdiv(a.npt, 8) * 8 * a.ncb;
-  hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, STRIDE, RG, BCO, WCO, WPX, TH, TW, HK>), dim3(grid),
+  hipLaunchKernelGGL((conv_igemm_kernel<T, KH, KW, STRIDE, RG, BCO, WCO, WPX, TH, TW, HK, UP>), dim3(grid),
                      dim3(64 * WCO * WPX), 0, stream, a);
   return ffa_check_launch("conv_igemm");
+}
+
+// two-source (nearest x2 + concat) launch: 3x3 stride 1 only; the caller checked that C1 is a whole number of
+// HK-chunk groups
+template <typename T, int BCO, int TH, int TW>
+static int launch_up(const ConvArgs& a, hipStream_t stream) {
+  if (a.nchunks % 4 == 0) return launch_hk<T, 3, 3, 1, 3, BCO, 1, 4, TH, TW, 4, true>(a, stream);
+  return launch_hk<T, 3, 3, 1, 3, BCO, 1, 4, TH, TW, 2, true>(a, stream);
 }
 
 template <typename T, int KH, int KW, int STRIDE, int RG, int BCO, int WCO, int WPX, int TH, int TW>
@@ -682,6 +708,8 @@ static int conv2d_impl(int dtype, const void* in, const void* w_packed, const fl
   a.out = out;
   a.bias = bias;
   a.stats = stat_partials;
+  a.in2 = nullptr;
+  a.c1_bytes = 0;
   a.res = residual;
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci;
   a.Ho = Ho; a.Wo = Wo; a.Co = Co;
@@ -719,6 +747,58 @@ extern "C" int ffa_conv2d_stats(int dtype, const void* in, const void* w_packed,
   FFA_REQUIRE(stat_partials, "conv_stats: null statistics buffer");
   return conv2d_impl(dtype, in, w_packed, bias, residual, out, stat_partials, B, Hi, Wi, Ci, Ho, Wo, Co, co_rows, bco,
                      kh, kw, stride, pad, dil, relu, stream);
+}
+
+// 3x3 stride-1 pad-1 convolution over the VIRTUAL input cat(nearest_x2(lo), skip) of a U-Net decoder block
+// (smp DecoderBlock.forward: F.interpolate(scale_factor=2, mode="nearest"), torch.cat, conv1): lo is
+// [B][Hl][Wl][C1], skip [B][2Hl][2Wl][C2] (null when C2 == 0), the packed weight has C1 + C2 input channels in that
+// order.  Returns FFA_ERR_UNSUPPORTED when C1 does not cover whole channel groups of the kernel's halo staging
+// (the caller then materialises the concat with ffa_upsample_nearest2x_concat_fwd).  stat_partials may be null.
+extern "C" int ffa_conv2d_upcat(int dtype, const void* lo, const void* skip, const void* w_packed, void* out,
+                                float* stat_partials, int B, int Hl, int Wl, int C1, int C2, int Co, int co_rows,
+                                int bco, hipStream_t stream) {
+  FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "conv_upcat: bad dtype %d", dtype);
+  FFA_REQUIRE(lo && w_packed && out && (skip || C2 == 0), "conv_upcat: null pointer");
+  FFA_REQUIRE(B > 0 && Hl > 0 && Wl > 0 && C1 > 0 && C2 >= 0 && C1 % 16 == 0 && C2 % 16 == 0 && Co % 8 == 0,
+              "conv_upcat: bad dims");
+  const int eb = (dtype == FFA_BF16) ? 2 : 4;
+  const int Hi = 2 * Hl, Wi = 2 * Wl, Ci = C1 + C2;
+  FFA_REQUIRE((long long)B * Hi * Wi * (C1 > C2 ? C1 : C2) * eb < (1LL << 31),
+              "conv_upcat: source tensors must be smaller than 2 GiB (32-bit piece offsets)");
+  if (!conv_supported(3, 3, 1, bco) || co_rows % bco != 0) {
+    ffa_set_error("conv_upcat: unsupported block %d / rows %d", bco, co_rows);
+    return FFA_ERR_UNSUPPORTED;
+  }
+  const int nchunks = Ci * eb / 32;
+  const int hk = (nchunks % 4 == 0) ? 4 : (nchunks % 2 == 0 ? 2 : 1);
+  if (hk == 1 || (C1 * eb) % (hk * 32) != 0) {
+    ffa_set_error("conv_upcat: C1 = %d does not cover whole %d-byte channel groups", C1, hk * 32);
+    return FFA_ERR_UNSUPPORTED;
+  }
+  ConvArgs a;
+  a.in = lo;
+  a.in2 = skip;
+  a.c1_bytes = C1 * eb;
+  a.w = w_packed;
+  a.out = out;
+  a.bias = nullptr;
+  a.stats = stat_partials;
+  a.res = nullptr;
+  a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci;
+  a.Ho = Hi; a.Wo = Wi; a.Co = Co;
+  a.pad = 1; a.dil = 1; a.relu = 0;
+  a.nchunks = nchunks;
+  const int tw = (Wi >= 32) ? 32 : 16, th = (Wi >= 32) ? 8 : 16;
+  a.tiles_x = ffa_cdiv(Wi, tw);
+  a.tiles_y = ffa_cdiv(Hi, th);
+  a.npt = B * a.tiles_x * a.tiles_y;
+  a.ncb = co_rows / bco;
+#define FFA_UP_CASE(T_)                                                         \
+  if (bco == 64) return (tw == 32) ? launch_up<T_, 64, 8, 32>(a, stream) : launch_up<T_, 64, 16, 16>(a, stream); \
+  return (tw == 32) ? launch_up<T_, 32, 8, 32>(a, stream) : launch_up<T_, 32, 16, 16>(a, stream);
+  if (dtype == FFA_BF16) { FFA_UP_CASE(ffa_bf16) }
+  FFA_UP_CASE(float)
+#undef FFA_UP_CASE
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -168,6 +168,30 @@ def conv2d(x: torch.Tensor, w: PackedWeight, pad: int, out_channels: int, bias: 
     return out
 
 
+def conv2d_upcat(lo: torch.Tensor, skip: Optional[torch.Tensor], w: PackedWeight, out_channels: int,
+                 stats: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """3x3 pad-1 conv over cat(nearest_x2(lo), skip) without materialising it.  Returns None when the library has no
+    two-source kernel for this channel split (the caller then concatenates explicitly)."""
+    lib = _l.load()
+    _chk_nhwc(lo, "upcat lo")
+    B, Hl, Wl, C1 = lo.shape
+    C2 = 0
+    if skip is not None:
+        _chk_nhwc(skip, "upcat skip")
+        if skip.shape[0] != B or skip.shape[1] != 2 * Hl or skip.shape[2] != 2 * Wl or skip.dtype != lo.dtype:
+            raise ValueError("conv2d_upcat: skip must be [B, 2*Hl, 2*Wl, C2] of the same dtype")
+        C2 = skip.shape[3]
+    if w.kh != 3 or w.kw != 3 or w.stride != 1 or w.ci_pitch != C1 + C2:
+        raise ValueError("conv2d_upcat: needs a 3x3 stride-1 operand packed for C1 + C2 input channels")
+    out = torch.empty((B, 2 * Hl, 2 * Wl, out_channels), dtype=lo.dtype, device=lo.device)
+    rc = lib.ffa_conv2d_upcat(_dt(lo), lo.data_ptr(), _ptr(skip), w.data.data_ptr(), out.data_ptr(), _ptr(stats), B, Hl,
+                              Wl, C1, C2, out_channels, w.rows, w.bco, _stream())
+    if rc == _l.ERR_UNSUPPORTED:
+        return None
+    _l.check(rc, "conv2d_upcat")
+    return out
+
+
 FUSED_BN_STATS = os.environ.get("FFA_FUSED_BN_STATS", "1") != "0"
 
 

@@ -449,3 +449,42 @@ def test_conv_epilogue_statistics_match_separate_pass(cuda, dtype, cin, cout, k,
         assert torch.allclose(a_[:cout], b_[:cout], rtol=2e-5, atol=2e-6), name
     assert torch.allclose(rm2[:cout], rm1[:cout], rtol=2e-5, atol=2e-7)
     assert torch.allclose(rv2[:cout], rv1[:cout], rtol=2e-5, atol=2e-7)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("c1,c2,cout,Hl,Wl", [
+    (128, 64, 64, 20, 24),    # 64-channel groups from both sources, 64-row blocks, ragged 8x32 tiles
+    (64, 64, 32, 16, 16),     # 32-row block
+    (32, 0, 16, 24, 16),      # last decoder block: no skip, 32-channel groups
+    (256, 128, 128, 6, 6),    # 16x16 tiles (width < 32)
+])
+def test_conv_over_virtual_upsample_concat(cuda, dtype, c1, c2, cout, Hl, Wl):
+    """ffa_conv2d_upcat(lo, skip) == ffa_conv2d(ffa_upsample_nearest2x_concat(lo, skip)), bit for bit (same
+    reduction order), including the statistics epilogue"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(c1 + c2)
+    B = 3
+    lo = to_nhwc(torch.randn(B, c1, Hl, Wl, generator=g), dtype, cuda, c1)
+    skip = to_nhwc(torch.randn(B, c2, 2 * Hl, 2 * Wl, generator=g), dtype, cuda, c2) if c2 else None
+    w = (torch.randn(cout, c1 + c2, 3, 3, generator=g) / ((c1 + c2) * 9) ** 0.5).to(cuda)
+    cop = ops.pad_channels(cout)
+    pw = ops.pack_conv_weight(w, dtype, 1, c1 + c2)
+    cat = ops.upsample2x_concat_fwd(lo, skip)
+    rows = ops.conv_stat_rows(B, 2 * Hl, 2 * Wl)
+    st_ref = torch.zeros(rows * 2 * cop, device=cuda)
+    st = torch.zeros(rows * 2 * cop, device=cuda)
+    ref = ops.conv2d(cat, pw, 1, cop, stats=st_ref)
+    got = ops.conv2d_upcat(lo, skip, pw, cop, stats=st)
+    torch.cuda.synchronize()
+    assert got is not None
+    assert torch.equal(got, ref)
+    assert torch.equal(st, st_ref)
+
+
+def test_conv_upcat_reports_unsupported_split(cuda):
+    from flairhip import ops
+    lo = torch.zeros(1, 4, 4, 16, device=cuda, dtype=torch.bfloat16)      # 16 channels < one 32-channel group
+    skip = torch.zeros(1, 8, 8, 16, device=cuda, dtype=torch.bfloat16)
+    w = torch.zeros(16, 32, 3, 3, device=cuda)
+    pw = ops.pack_conv_weight(w, torch.bfloat16, 1, 32)
+    assert ops.conv2d_upcat(lo, skip, pw, 16) is None
