@@ -44,6 +44,10 @@ struct WgradArgs {
   int pad;
   int tiles_x, tiles_y, npt;
   int ncob, ncib, nsplit;
+  // two-source input (x = nearest_x2(lo) ++ skip of a U-Net decoder block): x is lo [B][Hi/2][Wi/2][C1], x2 the
+  // skip tensor [B][Hi][Wi][Ci - C1] (null when C1 == Ci); x2 == null && C1 == 0: ordinary single input
+  const void* x2;
+  int C1;
   int CoT, CiT;
 };
 
@@ -123,6 +127,15 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
 
   const unsigned char* x_b = static_cast<const unsigned char*>(a.x);
   const unsigned char* dy_b = static_cast<const unsigned char*>(a.dy);
+  // Two-source input: every 32-channel plane of this block lies in ONE source (the host checks that C1 is a
+  // multiple of the block's channel extent), so the block picks base pointer, pixel pitch, image size and the
+  // channel origin once.  srcA = the low-res map, read at (y >> 1, x >> 1).
+  const bool srcA = a.C1 > 0 && ci0 < a.C1;
+  const bool srcB = a.C1 > 0 && !srcA;
+  if (srcB) x_b = static_cast<const unsigned char*>(a.x2);
+  const int xC = srcA ? a.C1 : (srcB ? a.Ci - a.C1 : a.Ci);  // channel pitch of the source actually read
+  const int xc0 = srcB ? ci0 - a.C1 : ci0;                   // first channel of the block inside that source
+  const int xH = srcA ? (a.Hi >> 1) : a.Hi, xW = srcA ? (a.Wi >> 1) : a.Wi;
 
   // fragment addressing (see file header)
   const int li = lane & 15;
@@ -160,10 +173,14 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
     const int part = i % G::PARTS;
     const int q = (i / G::PARTS) % (G::IH * G::IW);
     const int plane = i / (G::PARTS * G::IH * G::IW);
-    const int c = ci0 + plane * 32 + part * (16 / EB);
+    const int c = xc0 + plane * 32 + part * (16 / EB);
     const int r = (q / G::IW) * G::GSTEP, col = (q % G::IW) * G::GSTEP;
+    const bool exists = i < G::IN_PIECES && c < xC;
     ipos[k] = (unsigned short)((r << 8) | col);
-    irel[k] = (i < G::IN_PIECES && c < a.Ci) ? ((r * a.Wi + col) * a.Ci + c) * EB : -1;
+    // low-res source: the halo origin is odd (tile origin - 1), so (origin + r) >> 1 = (origin + 1) / 2 + ((r - 1) >> 1)
+    const int rr = srcA ? ((r - 1) >> 1) : r, cc = srcA ? ((col - 1) >> 1) : col;
+    // signed offset (negative for the first halo row / column of the low-res source); INT_MIN = never exists
+    irel[k] = exists ? ((rr * xW + cc) * xC + c) * EB : (int)0x80000000;
   }
   static_assert(!PRE || (G::IH * G::GSTEP < 256 && G::IW * G::GSTEP < 256), "packed piece position");
 
@@ -196,11 +213,12 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
       const int plane = i / (G::PARTS * G::IH * G::IW);                                                        \
       const int vy = iy0_ + (q / G::IW) * G::GSTEP;                                                            \
       const int vx = ix0_ + (q % G::IW) * G::GSTEP;                                                            \
-      const int c = ci0 + plane * 32 + part * (16 / EB);                                                       \
+      const int c = xc0 + plane * 32 + part * (16 / EB);                                                       \
       ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};                                                                 \
-      if (i < G::IN_PIECES && vy >= 0 && vx >= 0 && vy < a.Hi && vx < a.Wi && c < a.Ci)                        \
-        v = *reinterpret_cast<const ffa_u32x4*>(x_b +                                                          \
-                                                (((size_t)(b_ * a.Hi + vy) * a.Wi + vx) * a.Ci + c) * EB);     \
+      if (i < G::IN_PIECES && vy >= 0 && vx >= 0 && vy < a.Hi && vx < a.Wi && c < xC) {                        \
+        const int sy_ = srcA ? (vy >> 1) : vy, sx_ = srcA ? (vx >> 1) : vx;                                    \
+        v = *reinterpret_cast<const ffa_u32x4*>(x_b + (((size_t)(b_ * xH + sy_) * xW + sx_) * xC + c) * EB);   \
+      }                                                                                                        \
       ireg[k] = v;                                                                                             \
     }                                                                                                          \
   }
@@ -215,7 +233,8 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
     const int iy0_ = oy0_ * STRIDE - a.pad + rg * RG;                                                          \
     const int ix0_ = ox0_ * STRIDE - a.pad;                                                                    \
     const unsigned char* dyt_ = dy_b + ((long long)(b_ * a.Ho + oy0_) * a.Wo + ox0_) * (long long)(a.Co * EB); \
-    const unsigned char* xt_ = x_b + ((long long)(b_ * a.Hi + iy0_) * a.Wi + ix0_) * (long long)(a.Ci * EB);   \
+    const int by_ = srcA ? ((iy0_ + 1) >> 1) : iy0_, bx_ = srcA ? ((ix0_ + 1) >> 1) : ix0_;                    \
+    const unsigned char* xt_ = x_b + ((long long)(b_ * xH + by_) * xW + bx_) * (long long)(xC * EB);           \
     _Pragma("unroll") for (int k = 0; k < G::NDP; ++k) {                                                       \
       ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};                                                                 \
       if (drel[k] >= 0 && oy0_ + (dpos[k] >> 8) < a.Ho && ox0_ + (dpos[k] & 0xff) < a.Wo)                      \
@@ -224,9 +243,9 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
     }                                                                                                          \
     _Pragma("unroll") for (int k = 0; k < G::NIP; ++k) {                                                       \
       ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};                                                                 \
-      if (irel[k] >= 0 && (unsigned)(iy0_ + (ipos[k] >> 8)) < (unsigned)a.Hi &&                                \
+      if (irel[k] != (int)0x80000000 && (unsigned)(iy0_ + (ipos[k] >> 8)) < (unsigned)a.Hi &&                  \
           (unsigned)(ix0_ + (ipos[k] & 0xff)) < (unsigned)a.Wi)                                                \
-        v = *reinterpret_cast<const ffa_u32x4*>(xt_ + (unsigned)irel[k]);                                      \
+        v = *reinterpret_cast<const ffa_u32x4*>(xt_ + (long long)irel[k]);                                     \
       ireg[k] = v;                                                                                             \
     }                                                                                                          \
   }
@@ -926,9 +945,9 @@ static int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int kh, int kw, 
 
 // x: [B][Hi][Wi][Ci] (the conv input), dy: [B][Ho][Wo][Co]; Ci / Co are channel pitches, the
 // gradient is written for the first Co_real x Ci_real entries as OIHW f32 (accumulate != 0 adds to it).
-extern "C" int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int B, int Hi, int Wi, int Ci,
-                              int Ho, int Wo, int Co, int Co_real, int Ci_real, int kh, int kw, int stride, int pad,
-                              int accumulate, void* workspace, long long workspace_bytes, hipStream_t stream) {
+static int wgrad_impl(int dtype, const void* x, const void* x2, int C1, const void* dy, float* dw_oihw, int B, int Hi,
+                      int Wi, int Ci, int Ho, int Wo, int Co, int Co_real, int Ci_real, int kh, int kw, int stride,
+                      int pad, int accumulate, void* workspace, long long workspace_bytes, hipStream_t stream) {
   FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "conv_wgrad: bad dtype");
   FFA_REQUIRE(x && dy && dw_oihw && workspace, "conv_wgrad: null pointer");
   FFA_REQUIRE(Ci % 8 == 0 && Co % 8 == 0, "conv_wgrad: channel pitch must be a multiple of 8");
@@ -939,6 +958,13 @@ extern "C" int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* d
     return FFA_ERR_UNSUPPORTED;
   }
   if (pad != 1) p.ring = 0;  // the ring kernel's edge masks assume a one-pixel halo
+  if (C1 > 0) {
+    p.ring = 0;
+    if (C1 % (32 * p.wci) != 0) {
+      ffa_set_error("conv_wgrad_upcat: C1 = %d is not a multiple of the block's %d input channels", C1, 32 * p.wci);
+      return FFA_ERR_UNSUPPORTED;
+    }
+  }
   const long long need = (long long)p.nslab * p.CoT * kh * kw * p.CiT * (long long)sizeof(float);
   if (workspace_bytes < need) {
     ffa_set_error("conv_wgrad: workspace too small (%lld < %lld)", workspace_bytes, need);
@@ -946,6 +972,7 @@ extern "C" int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* d
   }
   WgradArgs a;
   a.x = x; a.dy = dy; a.slabs = static_cast<float*>(workspace);
+  a.x2 = x2; a.C1 = C1;
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci;
   a.Ho = Ho; a.Wo = Wo; a.Co = Co;
   a.pad = pad;
@@ -968,6 +995,24 @@ extern "C" int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* d
                        p.nslab, p.CoT, p.CiT, Co_real, Ci_real, kh * kw, accumulate);
   }
   return ffa_check_launch("wgrad_reduce");
+}
+
+extern "C" int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int B, int Hi, int Wi, int Ci,
+                              int Ho, int Wo, int Co, int Co_real, int Ci_real, int kh, int kw, int stride, int pad,
+                              int accumulate, void* workspace, long long workspace_bytes, hipStream_t stream) {
+  return wgrad_impl(dtype, x, nullptr, 0, dy, dw_oihw, B, Hi, Wi, Ci, Ho, Wo, Co, Co_real, Ci_real, kh, kw, stride, pad,
+                    accumulate, workspace, workspace_bytes, stream);
+}
+
+// Weight gradient of the 3x3 stride-1 pad-1 convolution whose input is the virtual cat(nearest_x2(lo), skip)
+// (see ffa_conv2d_upcat): lo [B][Hl][Wl][C1], skip [B][2Hl][2Wl][C2] or null; dw is OIHW [Co_real][C1 + C2][3][3].
+// Workspace: ffa_conv_wgrad_workspace_bytes(dtype, 3, 3, 1, Co, C1 + C2, B, 2Hl, 2Wl).
+extern "C" int ffa_conv_wgrad_upcat(int dtype, const void* lo, const void* skip, const void* dy, float* dw_oihw, int B,
+                                    int Hl, int Wl, int C1, int C2, int Co, int Co_real, int accumulate,
+                                    void* workspace, long long workspace_bytes, hipStream_t stream) {
+  FFA_REQUIRE(lo && (skip || C2 == 0) && C1 > 0 && C2 >= 0, "conv_wgrad_upcat: bad arguments");
+  return wgrad_impl(dtype, lo, skip, C1, dy, dw_oihw, B, 2 * Hl, 2 * Wl, C1 + C2, 2 * Hl, 2 * Wl, Co, Co_real, C1 + C2,
+                    3, 3, 1, 1, accumulate, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -243,6 +243,29 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, co_real: int, ci_real: int, kh
     return out
 
 
+def conv_wgrad_upcat(lo: torch.Tensor, skip: Optional[torch.Tensor], dy: torch.Tensor, co_real: int
+                     ) -> Optional[torch.Tensor]:
+    """dW [co_real, C1 + C2, 3, 3] of the conv over cat(nearest_x2(lo), skip); None when unsupported."""
+    lib = _l.load()
+    _chk_nhwc(lo, "wgrad lo")
+    _chk_nhwc(dy, "wgrad dy")
+    B, Hl, Wl, C1 = lo.shape
+    C2 = 0 if skip is None else skip.shape[3]
+    Co = dy.shape[3]
+    did = _dt(lo)
+    need = lib.ffa_conv_wgrad_workspace_bytes(did, 3, 3, 1, Co, C1 + C2, B, 2 * Hl, 2 * Wl)
+    if need < 0:
+        return None
+    ws = workspace(need, lo.device, "wgrad")
+    out = torch.empty((co_real, C1 + C2, 3, 3), dtype=torch.float32, device=lo.device)
+    rc = lib.ffa_conv_wgrad_upcat(did, lo.data_ptr(), _ptr(skip), dy.data_ptr(), out.data_ptr(), B, Hl, Wl, C1, C2, Co,
+                                  co_real, 0, ws.data_ptr(), ws.numel(), _stream())
+    if rc == _l.ERR_UNSUPPORTED:
+        return None
+    _l.check(rc, "conv_wgrad_upcat")
+    return out
+
+
 # --------------------------------------------------------------------------------------------------
 # normalisation / pooling
 

@@ -86,6 +86,13 @@ int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int
                    int Wo, int Co, int Co_real, int Ci_real, int kh, int kw, int stride, int pad, int accumulate,
                    void* workspace, long long workspace_bytes, ffa_stream_t stream);
 
+/* Weight gradient of the convolution ffa_conv2d_upcat computes: the input is the virtual cat(nearest_x2(lo), skip),
+ * dw is OIHW [Co_real][C1 + C2][3][3] f32.  Workspace: ffa_conv_wgrad_workspace_bytes(dtype, 3, 3, 1, Co, C1 + C2, B,
+ * 2*Hl, 2*Wl).  FFA_ERR_UNSUPPORTED when C1 is not a multiple of the kernel's input-channel block. */
+int ffa_conv_wgrad_upcat(int dtype, const void* lo, const void* skip, const void* dy, float* dw_oihw, int B, int Hl,
+                         int Wl, int C1, int C2, int Co, int Co_real, int accumulate, void* workspace,
+                         long long workspace_bytes, ffa_stream_t stream);
+
 /* ---- BatchNorm2d + ReLU + residual, MaxPool2d(3,2,1) (smp ResNet-34 encoder / UnetDecoder blocks;
  *      SURVEY.md Appendix C) ----------------------------------------------------------------------- */
 long long ffa_bn_workspace_bytes(int C);

@@ -488,3 +488,27 @@ def test_conv_upcat_reports_unsupported_split(cuda):
     w = torch.zeros(16, 32, 3, 3, device=cuda)
     pw = ops.pack_conv_weight(w, torch.bfloat16, 1, 32)
     assert ops.conv2d_upcat(lo, skip, pw, 16) is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("c1,c2,cout,Hl,Wl", [
+    (128, 64, 64, 20, 24),
+    (64, 64, 32, 16, 16),
+    (32, 0, 16, 24, 16),
+    (256, 128, 128, 6, 6),
+])
+def test_wgrad_over_virtual_upsample_concat(cuda, dtype, c1, c2, cout, Hl, Wl):
+    """ffa_conv_wgrad_upcat(lo, skip, dy) == ffa_conv_wgrad(concat, dy): same slabs, same fixed-order reduce"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(c1 * 3 + c2)
+    B = 3
+    lo = to_nhwc(torch.randn(B, c1, Hl, Wl, generator=g), dtype, cuda, c1)
+    skip = to_nhwc(torch.randn(B, c2, 2 * Hl, 2 * Wl, generator=g), dtype, cuda, c2) if c2 else None
+    cop = ops.pad_channels(cout)
+    dy = to_nhwc(torch.randn(B, cout, 2 * Hl, 2 * Wl, generator=g), dtype, cuda, cop)
+    cat = ops.upsample2x_concat_fwd(lo, skip)
+    ref = ops.conv_wgrad(cat, dy, cout, c1 + c2, 3, 3, 1, 1)
+    got = ops.conv_wgrad_upcat(lo, skip, dy, cout)
+    torch.cuda.synchronize()
+    assert got is not None
+    assert torch.equal(got, ref)
