@@ -753,10 +753,11 @@ extern "C" int ffa_conv2d_stats(int dtype, const void* in, const void* w_packed,
 // (smp DecoderBlock.forward: F.interpolate(scale_factor=2, mode="nearest"), torch.cat, conv1): lo is
 // [B][Hl][Wl][C1], skip [B][2Hl][2Wl][C2] (null when C2 == 0), the packed weight has C1 + C2 input channels in that
 // order.  Returns FFA_ERR_UNSUPPORTED when C1 does not cover whole channel groups of the kernel's halo staging
-// (the caller then materialises the concat with ffa_upsample_nearest2x_concat_fwd).  stat_partials may be null.
-extern "C" int ffa_conv2d_upcat(int dtype, const void* lo, const void* skip, const void* w_packed, void* out,
-                                float* stat_partials, int B, int Hl, int Wl, int C1, int C2, int Co, int co_rows,
-                                int bco, hipStream_t stream) {
+// (the caller then materialises the concat with ffa_upsample_nearest2x_concat_fwd).  bias (eval-mode folded
+// BatchNorm shift) and stat_partials may be null; relu applies in the epilogue.
+extern "C" int ffa_conv2d_upcat(int dtype, const void* lo, const void* skip, const void* w_packed, const float* bias,
+                                void* out, float* stat_partials, int B, int Hl, int Wl, int C1, int C2, int Co,
+                                int co_rows, int bco, int relu, hipStream_t stream) {
   FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "conv_upcat: bad dtype %d", dtype);
   FFA_REQUIRE(lo && w_packed && out && (skip || C2 == 0), "conv_upcat: null pointer");
   FFA_REQUIRE(B > 0 && Hl > 0 && Wl > 0 && C1 > 0 && C2 >= 0 && C1 % 16 == 0 && C2 % 16 == 0 && Co % 8 == 0,
@@ -781,12 +782,12 @@ extern "C" int ffa_conv2d_upcat(int dtype, const void* lo, const void* skip, con
   a.c1_bytes = C1 * eb;
   a.w = w_packed;
   a.out = out;
-  a.bias = nullptr;
+  a.bias = bias;
   a.stats = stat_partials;
   a.res = nullptr;
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci;
   a.Ho = Hi; a.Wo = Wi; a.Co = Co;
-  a.pad = 1; a.dil = 1; a.relu = 0;
+  a.pad = 1; a.dil = 1; a.relu = relu;
   a.nchunks = nchunks;
   const int tw = (Wi >= 32) ? 32 : 16, th = (Wi >= 32) ? 8 : 16;
   a.tiles_x = ffa_cdiv(Wi, tw);

@@ -170,6 +170,39 @@ class _ConvBnAct(torch.autograd.Function):
         return dx, dw, dgamma, dbeta, dres, None, None, None
 
 
+class _UpConvBnAct(torch.autograd.Function):
+    """y = relu(bn_train(conv3x3(cat(nearest_x2(lo), skip)))) -- the first half of a U-Net DecoderBlock -- with the
+    upsampled + concatenated tensor never materialised: forward conv and wgrad read lo (at y/2, x/2) and skip
+    directly.  Only the input gradient still passes through a full-resolution dcat (split by up2_concat_bwd)."""
+
+    @staticmethod
+    def forward(ctx, lo, skip, weight, gamma, beta, conv: HipConv2d, bn: HipBatchNorm2d):
+        y0, scale, shift, mean, rstd = ops.conv2d_upcat_bn_stats(lo, skip, conv.packed(lo.dtype), conv.out_pitch, gamma,
+                                                                 beta, bn.running_mean, bn.running_var, bn.momentum,
+                                                                 bn.eps)
+        bn.note_batch()
+        y = ops.bn_apply(y0, scale, shift, relu=True)
+        ctx.conv = conv
+        ctx.save_for_backward(lo, skip, y0, gamma, beta, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lo, skip, y0, gamma, beta, mean, rstd = ctx.saved_tensors
+        conv = ctx.conv
+        d0, _, dgamma, dbeta = ops.bn_bwd(y0, _as_nhwc_grad(dy), None, gamma, beta, mean, rstd, True, False)
+        dlo = dskip = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dcat = ops.conv2d(d0, conv.packed(d0.dtype, transpose=True), 1, conv.in_pitch)
+            dlo, dskip = ops.upsample2x_concat_bwd(dcat, lo.shape[-1], skip_as_view=True)
+        dw = None
+        if ctx.needs_input_grad[2]:
+            dw = ops.conv_wgrad_upcat(lo, skip, d0, conv.out_channels)
+            if dw is None:
+                raise RuntimeError("conv_wgrad_upcat refused a channel split that upcat_supported accepted")
+        return dlo, dskip, dw, dgamma, dbeta, None, None
+
+
 class _BasicBlock(torch.autograd.Function):
     """One ResNet BasicBlock in training mode as a single autograd node:
         y = relu( bn2(conv2( relu(bn1(conv1(x))) )) + identity ),   identity = x  or  bn_d(conv_d(x)).
@@ -399,18 +432,39 @@ def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, relu: bool = True, resid
     (scale into the packed weights, shift as bias) with the residual add / ReLU in the conv epilogue."""
     if bn.training:
         return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, conv, bn, relu)
+    pw, shift = _eval_folded(conv, bn, x.dtype)
+    return ops.conv2d(x, pw, conv.padding, conv.out_pitch, bias=shift, residual=residual, relu=relu)
+
+
+def _eval_folded(conv: HipConv2d, bn: HipBatchNorm2d, dtype: torch.dtype):
+    """(packed weights with the eval-mode BatchNorm scale folded in, shift vector), cached per parameter version"""
     ver = (conv.weight._version, conv.weight.data_ptr(), bn.weight._version, bn.bias._version,
-           bn.running_mean._version, bn.running_var._version, x.dtype)
+           bn.running_mean._version, bn.running_var._version, dtype)
     hit = conv._cache.get("eval_fold")
     if hit is None or hit[0] != ver:
         scale, shift = ops.bn_eval_params(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                           bn.eps)
         w = conv.weight.detach()
-        pw = ops.pack_conv_weight(w if w.is_contiguous() else w.contiguous(), x.dtype, conv.stride, conv.in_pitch,
+        pw = ops.pack_conv_weight(w if w.is_contiguous() else w.contiguous(), dtype, conv.stride, conv.in_pitch,
                                   scale=scale)
         hit = (ver, pw, shift)
         conv._cache["eval_fold"] = hit
-    return ops.conv2d(x, hit[1], conv.padding, conv.out_pitch, bias=hit[2], residual=residual, relu=relu)
+    return hit[1], hit[2]
+
+
+def up_conv_bn_act(lo, skip, conv: HipConv2d, bn: HipBatchNorm2d):
+    """relu(bn(conv3x3(cat(nearest_x2(lo), skip)))): two-source kernels when the channel split allows, otherwise the
+    explicit upsample + concat followed by conv_bn_act."""
+    c1, c2 = lo.shape[-1], (0 if skip is None else skip.shape[-1])
+    if conv.kernel_size == 3 and conv.stride == 1 and conv.padding == 1 and conv.in_channels == c1 + c2 and \
+            ops.upcat_supported(c1, c2, lo.dtype):
+        if bn.training:
+            return _UpConvBnAct.apply(lo, skip, conv.weight, bn.weight, bn.bias, conv, bn)
+        pw, shift = _eval_folded(conv, bn, lo.dtype)
+        y = ops.conv2d_upcat(lo, skip, pw, conv.out_pitch, bias=shift, relu=True)
+        if y is not None:
+            return y
+    return conv_bn_act(up_concat(lo, skip), conv, bn, relu=True)
 
 
 def basic_block(x, blk):

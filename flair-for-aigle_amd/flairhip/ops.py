@@ -169,7 +169,8 @@ def conv2d(x: torch.Tensor, w: PackedWeight, pad: int, out_channels: int, bias: 
 
 
 def conv2d_upcat(lo: torch.Tensor, skip: Optional[torch.Tensor], w: PackedWeight, out_channels: int,
-                 stats: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                 stats: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, relu: bool = False
+                 ) -> Optional[torch.Tensor]:
     """3x3 pad-1 conv over cat(nearest_x2(lo), skip) without materialising it.  Returns None when the library has no
     two-source kernel for this channel split (the caller then concatenates explicitly)."""
     lib = _l.load()
@@ -184,8 +185,10 @@ def conv2d_upcat(lo: torch.Tensor, skip: Optional[torch.Tensor], w: PackedWeight
     if w.kh != 3 or w.kw != 3 or w.stride != 1 or w.ci_pitch != C1 + C2:
         raise ValueError("conv2d_upcat: needs a 3x3 stride-1 operand packed for C1 + C2 input channels")
     out = torch.empty((B, 2 * Hl, 2 * Wl, out_channels), dtype=lo.dtype, device=lo.device)
-    rc = lib.ffa_conv2d_upcat(_dt(lo), lo.data_ptr(), _ptr(skip), w.data.data_ptr(), out.data_ptr(), _ptr(stats), B, Hl,
-                              Wl, C1, C2, out_channels, w.rows, w.bco, _stream())
+    if bias is not None and bias.numel() < out_channels:
+        raise ValueError("conv2d_upcat: bias shorter than the output pitch")
+    rc = lib.ffa_conv2d_upcat(_dt(lo), lo.data_ptr(), _ptr(skip), w.data.data_ptr(), _ptr(bias), out.data_ptr(),
+                              _ptr(stats), B, Hl, Wl, C1, C2, out_channels, w.rows, w.bco, 1 if relu else 0, _stream())
     if rc == _l.ERR_UNSUPPORTED:
         return None
     _l.check(rc, "conv2d_upcat")
@@ -199,27 +202,63 @@ def conv_stat_rows(B: int, Ho: int, Wo: int) -> int:
     return int(_l.load().ffa_conv_stat_rows(B, Ho, Wo))
 
 
+def _bn_finalize(part: torch.Tensor, rows: int, npix: int, channels: int, gamma, beta, running_mean, running_var,
+                 momentum: float, eps: float):
+    lib = _l.load()
+    dev = part.device
+    out = torch.empty((4, channels), dtype=torch.float32, device=dev)
+    ws = workspace(lib.ffa_bn_workspace_bytes(channels), dev, "bn")
+    _l.check(lib.ffa_bn_finalize(part.data_ptr(), rows, npix, channels, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                 _ptr(running_var), momentum, eps, out[0].data_ptr(), out[1].data_ptr(),
+                                 out[2].data_ptr(), out[3].data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+             "bn_finalize")
+    return out[0], out[1], out[2], out[3]
+
+
 def conv2d_bn_stats(x: torch.Tensor, w: PackedWeight, pad: int, out_channels: int, gamma, beta, running_mean,
                     running_var, momentum: float, eps: float):
     """conv + the batch statistics of its output in one kernel: -> (y0, scale, shift, mean, rstd); the running
     buffers are updated in place.  Equivalent to conv2d followed by bn_stats, minus one pass over y0."""
-    lib = _l.load()
     if not FUSED_BN_STATS:  # A/B switch (FFA_FUSED_BN_STATS=0): the two-kernel path
         y0 = conv2d(x, w, pad, out_channels)
         return (y0,) + tuple(bn_stats(y0, gamma, beta, running_mean, running_var, momentum, eps))
     B, Hi, Wi, _ = x.shape
     Ho, Wo = conv_out_size(Hi, w.kh, w.stride, pad), conv_out_size(Wi, w.kw, w.stride, pad)
     rows = conv_stat_rows(B, Ho, Wo)
-    dev = x.device
-    part = workspace(rows * 2 * out_channels * 4, dev, "bnpart").view(torch.float32)
+    part = workspace(rows * 2 * out_channels * 4, x.device, "bnpart").view(torch.float32)
     y0 = conv2d(x, w, pad, out_channels, stats=part)
-    out = torch.empty((4, out_channels), dtype=torch.float32, device=dev)
-    ws = workspace(lib.ffa_bn_workspace_bytes(out_channels), dev, "bn")
-    _l.check(lib.ffa_bn_finalize(part.data_ptr(), rows, B * Ho * Wo, out_channels, _ptr(gamma), _ptr(beta),
-                                 _ptr(running_mean), _ptr(running_var), momentum, eps, out[0].data_ptr(),
-                                 out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), ws.data_ptr(), ws.numel(),
-                                 _stream()), "bn_finalize")
-    return y0, out[0], out[1], out[2], out[3]
+    return (y0,) + _bn_finalize(part, rows, B * Ho * Wo, out_channels, gamma, beta, running_mean, running_var,
+                                momentum, eps)
+
+
+def upcat_supported(c1: int, c2: int, dtype: torch.dtype) -> bool:
+    """Channel splits the two-source kernels take (ffa_conv2d_upcat: C1 covers whole halo channel groups;
+    ffa_conv_wgrad_upcat: C1 is a multiple of a block's input channels)."""
+    if not FUSED_UPCAT:
+        return False
+    eb = 2 if dtype == torch.bfloat16 else 4
+    ci = c1 + c2
+    nchunks = ci * eb // 32
+    hk = 4 if nchunks % 4 == 0 else (2 if nchunks % 2 == 0 else 1)
+    wci = 2 if (ci > 32 and eb == 2) else 1
+    return c1 > 0 and c1 % 16 == 0 and c2 % 16 == 0 and hk > 1 and (c1 * eb) % (hk * 32) == 0 and c1 % (32 * wci) == 0
+
+
+FUSED_UPCAT = os.environ.get("FFA_FUSED_UPCAT", "1") != "0"  # A/B switch: materialise the decoder concat instead
+
+
+def conv2d_upcat_bn_stats(lo: torch.Tensor, skip: Optional[torch.Tensor], w: PackedWeight, out_channels: int, gamma,
+                          beta, running_mean, running_var, momentum: float, eps: float):
+    """conv2d_upcat + batch statistics of its output -> (y0, scale, shift, mean, rstd)"""
+    B, Hl, Wl, _ = lo.shape
+    Ho, Wo = 2 * Hl, 2 * Wl
+    rows = conv_stat_rows(B, Ho, Wo)
+    part = workspace(rows * 2 * out_channels * 4, lo.device, "bnpart").view(torch.float32)
+    y0 = conv2d_upcat(lo, skip, w, out_channels, stats=part)
+    if y0 is None:
+        raise _l.FlairHipError("conv2d_upcat: unsupported channel split (check upcat_supported first)")
+    return (y0,) + _bn_finalize(part, rows, B * Ho * Wo, out_channels, gamma, beta, running_mean, running_var,
+                                momentum, eps)
 
 
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, co_real: int, ci_real: int, kh: int, kw: int, stride: int,

@@ -81,8 +81,9 @@ class DecoderBlock(nn.Module):
         self.conv2 = nn.Sequential(hnn.HipConv2d(cout, cout, 3, 1, 1), hnn.HipBatchNorm2d(cout))
 
     def forward(self, x, skip: Optional[torch.Tensor] = None):
-        x = hnn.up_concat(x, skip)
-        x = hnn.conv_bn_act(x, self.conv1[0], self.conv1[1], relu=True)
+        # nearest x2 + concat + conv1 + BN + ReLU; the concatenated tensor is only materialised when the two-source
+        # kernels do not take the channel split
+        x = hnn.up_conv_bn_act(x, skip, self.conv1[0], self.conv1[1])
         return hnn.conv_bn_act(x, self.conv2[0], self.conv2[1], relu=True)
 
 

@@ -77,10 +77,11 @@ int ffa_conv2d_stats(int dtype, const void* in, const void* w_packed, const floa
 /* 3x3 stride-1 pad-1 convolution over the virtual tensor cat(nearest_x2(lo), skip) -- what smp's DecoderBlock builds
  * with F.interpolate(scale_factor=2, mode="nearest") + torch.cat before its first conv (reached from
  * flair_model.py:417-419) -- without writing it: lo [B][Hl][Wl][C1], skip [B][2Hl][2Wl][C2] or null.
- * FFA_ERR_UNSUPPORTED when C1 is not a whole number of the kernel's channel groups. stat_partials may be null. */
-int ffa_conv2d_upcat(int dtype, const void* lo, const void* skip, const void* w_packed, void* out,
+ * FFA_ERR_UNSUPPORTED when C1 is not a whole number of the kernel's channel groups.  bias (per output channel, e.g.
+ * an eval-mode BatchNorm shift) and stat_partials may be null; relu != 0 clamps in the epilogue. */
+int ffa_conv2d_upcat(int dtype, const void* lo, const void* skip, const void* w_packed, const float* bias, void* out,
                      float* stat_partials, int B, int Hl, int Wl, int C1, int C2, int Co, int co_rows, int bco,
-                     ffa_stream_t stream);
+                     int relu, ffa_stream_t stream);
 long long ffa_conv_wgrad_workspace_bytes(int dtype, int kh, int kw, int stride, int Co, int Ci, int B, int Ho, int Wo);
 int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int B, int Hi, int Wi, int Ci, int Ho,
                    int Wo, int Co, int Co_real, int Ci_real, int kh, int kw, int stride, int pad, int accumulate,

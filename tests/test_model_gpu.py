@@ -141,3 +141,37 @@ def test_product_path_rejects_cpu_tensors(cuda):
     x, t = _inputs(1, 32, 32)
     with pytest.raises(RuntimeError):
         task.model({MOD: x, TASK: t})
+
+
+def test_fused_decoder_prologue_and_bn_statistics_equal_the_unfused_path(cuda, monkeypatch):
+    """two-source conv (virtual nearest x2 + concat) and conv-epilogue BatchNorm statistics against the explicit
+    upsample/concat + separate statistics pass: same logits in eval mode bit for bit, same training loss / gradients
+    up to the summation order of the batch statistics"""
+    from flairhip import ops
+    task, oracle, cfg = make_pair(precision="bf16")
+    x, t = _inputs(2, 64, 96, seed=21)
+    batch = {MOD: x.to(cuda), TASK: t.to(cuda)}
+
+    def run(train):
+        task.train(train)
+        task.model.zero_grad(set_to_none=True)
+        if not train:
+            with torch.no_grad():
+                return task.model(batch)[0][TASK].float().clone(), None
+        loss, _, _ = task.step(batch, training=True)
+        loss.backward()
+        g = task.model.state_dict  # noqa: F841
+        w = dict(task.model.named_parameters())[f"main_decoders.{TASK}.seg_model.decoder.blocks.1.conv1.0.weight"]
+        return loss.detach().clone(), w.grad.clone()
+
+    fused_eval, _ = run(False)
+    state = {k: v.clone() for k, v in task.state_dict().items()}
+    fused_loss, fused_grad = run(True)
+    monkeypatch.setattr(ops, "FUSED_UPCAT", False)
+    monkeypatch.setattr(ops, "FUSED_BN_STATS", False)
+    task.load_state_dict(state)
+    plain_eval, _ = run(False)
+    plain_loss, plain_grad = run(True)
+    assert torch.equal(fused_eval, plain_eval)
+    assert abs(fused_loss.item() - plain_loss.item()) <= 2e-3 * abs(plain_loss.item())
+    assert ((fused_grad - plain_grad).norm() / plain_grad.norm()).item() <= 2e-2
