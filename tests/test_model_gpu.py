@@ -148,8 +148,10 @@ def test_fused_decoder_prologue_and_bn_statistics_equal_the_unfused_path(cuda, m
     upsample/concat + separate statistics pass: same logits in eval mode bit for bit, same training loss / gradients
     up to the summation order of the batch statistics"""
     from flairhip import ops
-    task, oracle, cfg = make_pair(precision="bf16")
-    x, t = _inputs(2, 64, 96, seed=21)
+    # fp32 and a 128x128 tile: with bf16 storage or a 2x3-pixel bottleneck the 1e-7 differences in the batch
+    # statistics are amplified chaotically through 50 BatchNorm layers and nothing meaningful can be compared
+    task, oracle, cfg = make_pair(precision="fp32")
+    x, t = _inputs(2, 128, 128, seed=21)
     batch = {MOD: x.to(cuda), TASK: t.to(cuda)}
 
     def run(train):
@@ -160,7 +162,6 @@ def test_fused_decoder_prologue_and_bn_statistics_equal_the_unfused_path(cuda, m
                 return task.model(batch)[0][TASK].float().clone(), None
         loss, _, _ = task.step(batch, training=True)
         loss.backward()
-        g = task.model.state_dict  # noqa: F841
         w = dict(task.model.named_parameters())[f"main_decoders.{TASK}.seg_model.decoder.blocks.1.conv1.0.weight"]
         return loss.detach().clone(), w.grad.clone()
 
@@ -173,5 +174,6 @@ def test_fused_decoder_prologue_and_bn_statistics_equal_the_unfused_path(cuda, m
     plain_eval, _ = run(False)
     plain_loss, plain_grad = run(True)
     assert torch.equal(fused_eval, plain_eval)
-    assert abs(fused_loss.item() - plain_loss.item()) <= 2e-3 * abs(plain_loss.item())
-    assert ((fused_grad - plain_grad).norm() / plain_grad.norm()).item() <= 2e-2
+    assert abs(fused_loss.item() - plain_loss.item()) <= 1e-5 * abs(plain_loss.item())
+    # same budget as the oracle comparison above: the summation order of the batch statistics differs
+    assert ((fused_grad - plain_grad).norm() / plain_grad.norm()).item() <= 1e-2
