@@ -50,6 +50,8 @@ struct ConvArgs {
   float* stats;       // [npt][2][Co] per-tile channel sums / sums of squares of the stored output, or null
   const void* in2;    // UP kernels: the skip tensor [B][Hi][Wi][C2]; `in` is then the low-res map [B][Hi/2][Wi/2][C1]
   int c1_bytes;       // UP kernels: bytes of one pixel of `in` (C1 * sizeof(T)); the virtual input has Ci = C1 + C2
+  void* out2;         // split epilogue (c1_out > 0): output channels >= c1_out go here, pixel pitch Co - c1_out
+  int c1_out;         // split epilogue: output channels < c1_out are 2x2-sum-pooled into `out` [B][Ho/2][Wo/2][c1_out]
   const void* res;    // same layout as out, or null
   int B, Hi, Wi, Ci;  // stored input dims (Ci = channel pitch)
   int Ho, Wo, Co;     // Co = stored output channel pitch
@@ -453,6 +455,82 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
   T* out = static_cast<T*>(a.out);
   const T* res = static_cast<const T*>(a.res);
   const int co_wave = cb * BCO + wco * G::WAVE_CO;
+  int opitch = a.Co, cshift = 0;  // pixel pitch of the tensor written and the channel it starts at
+  if (a.c1_out > 0) {
+    // Split epilogue = backward of "nearest x2 upsample + concat" fused into the dgrad of a decoder block's first
+    // conv: the gradient of the virtual input cat(up(lo), skip) never exists as a tensor.  Channel blocks below
+    // c1_out are summed over their 2x2 pixel quads (the adjoint of nearest x2) and written at half resolution,
+    // the rest goes to the skip-gradient tensor with its own pitch.
+    if (cb * BCO >= a.c1_out) {
+      out = static_cast<T*>(a.out2);
+      opitch = a.Co - a.c1_out;
+      cshift = a.c1_out;
+    } else {
+      static_assert(G::WAVE_PX == 64, "quad pooling assumes two 32-pixel fragments per wave");
+      constexpr int NV = (G::MT == 2) ? 8 : 4;
+      const int Hl = a.Ho >> 1, Wl = a.Wo >> 1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = (G::MT == 2) ? co_wave + 16 * g + 8 * half : co_wave + 8 * g + 4 * half;
+        float q[G::NT][NV];
+#pragma unroll
+        for (int nt = 0; nt < G::NT; ++nt) {
+          const int n = wpx * G::WAVE_PX + nt * 32 + rho;
+          const bool ok = (oy0 + n / TW) < a.Ho && (ox0 + n % TW) < a.Wo;
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            const float v = (G::MT == 2) ? acc[i >> 2][nt][4 * g + (i & 3)] : acc[0][nt][4 * g + i];
+            q[nt][i] = ok ? v : 0.f;
+          }
+        }
+        if (TW == 32) {  // fragment nt = tile row 2*wpx + nt, lane = column: vertical partner in registers
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            float t = q[0][i] + q[1][i];
+            t += __shfl_xor(t, 1, 64);
+            q[0][i] = t;
+          }
+          const int ly = (oy0 >> 1) + wpx, lx = (ox0 >> 1) + (rho >> 1);
+          if ((rho & 1) == 0 && ly < Hl && lx < Wl && c0 < a.c1_out) {
+            T* dst = out + ((size_t)(b * Hl + ly) * Wl + lx) * (size_t)a.c1_out + c0;
+            if (G::MT == 2) {
+              float v8[8];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) v8[i] = q[0][i & 7];
+              ffa_store8<T>(dst, v8);
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) ffa_store_elem<T>(dst + i, q[0][i]);
+            }
+          }
+        } else {  // 16x16 tiles: fragment nt = rows 4*wpx + 2*nt + (rho >> 4), lane & 15 = column
+#pragma unroll
+          for (int nt = 0; nt < G::NT; ++nt) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+              float t = q[nt][i] + __shfl_xor(q[nt][i], 16, 64);
+              t += __shfl_xor(t, 1, 64);
+              q[nt][i] = t;
+            }
+            const int ly = (oy0 >> 1) + 2 * wpx + nt, lx = (ox0 >> 1) + ((rho & 15) >> 1);
+            if ((rho & 17) == 0 && ly < Hl && lx < Wl && c0 < a.c1_out) {
+              T* dst = out + ((size_t)(b * Hl + ly) * Wl + lx) * (size_t)a.c1_out + c0;
+              if (G::MT == 2) {
+                float v8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v8[i] = q[nt][i & 7];
+                ffa_store8<T>(dst, v8);
+              } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ffa_store_elem<T>(dst + i, q[nt][i]);
+              }
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
   // BatchNorm batch statistics of the tensor being written, from the registers that hold it (a.stats != null):
   // per lane NCH channels x (sum, sum of squares) over its pixels, of the values AS STORED (bf16-rounded)
   constexpr int NCH = (G::MT == 2) ? 32 : 16;
@@ -465,7 +543,7 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
     const int n = wpx * G::WAVE_PX + nt * 32 + rho;
     const int oy = oy0 + n / TW, ox = ox0 + n % TW;
     if (oy >= a.Ho || ox >= a.Wo) continue;
-    const size_t pix = ((size_t)(b * a.Ho + oy) * a.Wo + ox) * (size_t)a.Co;
+    const long long pix = ((long long)(b * a.Ho + oy) * a.Wo + ox) * (long long)opitch - cshift;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       if (G::MT == 2) {
@@ -683,7 +761,7 @@ extern "C" int ffa_conv_row_group(int kh) { return conv_rg(kh); }
 static int conv2d_impl(int dtype, const void* in, const void* w_packed, const float* bias, const void* residual,
                        void* out, float* stat_partials, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
                        int co_rows, int bco, int kh, int kw, int stride, int pad, int dil, int relu,
-                       hipStream_t stream) {
+                       hipStream_t stream, void* out2 = nullptr, int c1_out = 0) {
   FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "conv: bad dtype %d", dtype);
   FFA_REQUIRE(in && w_packed && out, "conv: null pointer");
   FFA_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "conv: bad dims");
@@ -710,6 +788,8 @@ static int conv2d_impl(int dtype, const void* in, const void* w_packed, const fl
   a.stats = stat_partials;
   a.in2 = nullptr;
   a.c1_bytes = 0;
+  a.out2 = out2;
+  a.c1_out = c1_out;
   a.res = residual;
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci;
   a.Ho = Ho; a.Wo = Wo; a.Co = Co;
@@ -780,6 +860,8 @@ extern "C" int ffa_conv2d_upcat(int dtype, const void* lo, const void* skip, con
   a.in = lo;
   a.in2 = skip;
   a.c1_bytes = C1 * eb;
+  a.out2 = nullptr;
+  a.c1_out = 0;
   a.w = w_packed;
   a.out = out;
   a.bias = bias;
@@ -800,6 +882,23 @@ extern "C" int ffa_conv2d_upcat(int dtype, const void* lo, const void* skip, con
   if (dtype == FFA_BF16) { FFA_UP_CASE(ffa_bf16) }
   FFA_UP_CASE(float)
 #undef FFA_UP_CASE
+}
+
+// Input gradient of the convolution ffa_conv2d_upcat computes, delivered as the two gradients the decoder block
+// needs: dlo [B][Ho/2][Wo/2][C1] (2x2 sums = adjoint of nearest x2) and dskip [B][Ho][Wo][C2] (null when C2 == 0).
+// dy is [B][Ho][Wo][Cdy]; w_packed_t is the transposed (dgrad) operand with co_rows >= C1 + C2 rows.  The gradient
+// of the concatenated tensor is never written.  FFA_ERR_UNSUPPORTED unless C1 is a whole number of bco-row blocks.
+extern "C" int ffa_conv2d_dgrad_upcat(int dtype, const void* dy, const void* w_packed_t, void* dlo, void* dskip, int B,
+                                      int Ho, int Wo, int Cdy, int C1, int C2, int co_rows, int bco,
+                                      hipStream_t stream) {
+  FFA_REQUIRE(dy && w_packed_t && dlo && (dskip || C2 == 0), "dgrad_upcat: null pointer");
+  FFA_REQUIRE(Ho % 2 == 0 && Wo % 2 == 0 && C1 > 0 && C2 >= 0 && C1 % 8 == 0 && C2 % 8 == 0, "dgrad_upcat: bad dims");
+  if (C1 % bco != 0) {
+    ffa_set_error("dgrad_upcat: C1 = %d is not a multiple of the %d-row block", C1, bco);
+    return FFA_ERR_UNSUPPORTED;
+  }
+  return conv2d_impl(dtype, dy, w_packed_t, nullptr, nullptr, dlo, nullptr, B, Ho, Wo, Cdy, Ho, Wo, C1 + C2, co_rows,
+                     bco, 3, 3, 1, 1, 1, 0, stream, dskip, C1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -193,8 +193,13 @@ class _UpConvBnAct(torch.autograd.Function):
         d0, _, dgamma, dbeta = ops.bn_bwd(y0, _as_nhwc_grad(dy), None, gamma, beta, mean, rstd, True, False)
         dlo = dskip = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            dcat = ops.conv2d(d0, conv.packed(d0.dtype, transpose=True), 1, conv.in_pitch)
-            dlo, dskip = ops.upsample2x_concat_bwd(dcat, lo.shape[-1], skip_as_view=True)
+            pwt = conv.packed(d0.dtype, transpose=True)
+            c1, c2 = lo.shape[-1], (0 if skip is None else skip.shape[-1])
+            pair = ops.conv2d_dgrad_upcat(d0, pwt, c1, c2)  # dlo pooled in the dgrad epilogue, dskip written directly
+            if pair is None:
+                dcat = ops.conv2d(d0, pwt, 1, conv.in_pitch)
+                pair = ops.upsample2x_concat_bwd(dcat, c1, skip_as_view=True)
+            dlo, dskip = pair
         dw = None
         if ctx.needs_input_grad[2]:
             dw = ops.conv_wgrad_upcat(lo, skip, d0, conv.out_channels)

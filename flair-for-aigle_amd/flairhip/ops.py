@@ -195,6 +195,26 @@ def conv2d_upcat(lo: torch.Tensor, skip: Optional[torch.Tensor], w: PackedWeight
     return out
 
 
+def conv2d_dgrad_upcat(dy: torch.Tensor, wt: PackedWeight, c1: int, c2: int):
+    """Input gradient of conv2d_upcat -> (dlo [B,H/2,W/2,c1], dskip [B,H,W,c2] or None), or None when the channel
+    split is not supported (the caller then runs the plain dgrad + upsample2x_concat_bwd)."""
+    if not FUSED_UPCAT_BWD:
+        return None
+    lib = _l.load()
+    _chk_nhwc(dy, "dgrad_upcat dy")
+    B, H, W, Cdy = dy.shape
+    if Cdy != wt.ci_pitch or wt.kh != 3 or wt.stride != 1 or H % 2 or W % 2:
+        raise ValueError("conv2d_dgrad_upcat: operand / gradient mismatch")
+    dlo = torch.empty((B, H // 2, W // 2, c1), dtype=dy.dtype, device=dy.device)
+    dskip = torch.empty((B, H, W, c2), dtype=dy.dtype, device=dy.device) if c2 else None
+    rc = lib.ffa_conv2d_dgrad_upcat(_dt(dy), dy.data_ptr(), wt.data.data_ptr(), dlo.data_ptr(), _ptr(dskip), B, H, W, Cdy,
+                                    c1, c2, wt.rows, wt.bco, _stream())
+    if rc == _l.ERR_UNSUPPORTED:
+        return None
+    _l.check(rc, "conv2d_dgrad_upcat")
+    return dlo, dskip
+
+
 FUSED_BN_STATS = os.environ.get("FFA_FUSED_BN_STATS", "1") != "0"
 
 
@@ -244,6 +264,7 @@ def upcat_supported(c1: int, c2: int, dtype: torch.dtype) -> bool:
     return c1 > 0 and c1 % 16 == 0 and c2 % 16 == 0 and hk > 1 and (c1 * eb) % (hk * 32) == 0 and c1 % (32 * wci) == 0
 
 
+FUSED_UPCAT_BWD = os.environ.get("FFA_FUSED_UPCAT_BWD", "1") != "0"  # A/B: plain dgrad + up2_concat_bwd
 FUSED_UPCAT = os.environ.get("FFA_FUSED_UPCAT", "1") != "0"  # A/B switch: materialise the decoder concat instead
 
 

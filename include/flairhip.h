@@ -82,6 +82,12 @@ int ffa_conv2d_stats(int dtype, const void* in, const void* w_packed, const floa
 int ffa_conv2d_upcat(int dtype, const void* lo, const void* skip, const void* w_packed, const float* bias, void* out,
                      float* stat_partials, int B, int Hl, int Wl, int C1, int C2, int Co, int co_rows, int bco,
                      int relu, ffa_stream_t stream);
+
+/* Input gradient of that convolution as the two tensors the decoder block needs -- dlo [B][Ho/2][Wo/2][C1] (2x2 sums,
+ * the adjoint of nearest x2) and dskip [B][Ho][Wo][C2] -- without materialising the gradient of the concatenation
+ * (replaces ffa_conv2d(dgrad) + ffa_upsample_nearest2x_concat_bwd).  w_packed_t: the transposed operand. */
+int ffa_conv2d_dgrad_upcat(int dtype, const void* dy, const void* w_packed_t, void* dlo, void* dskip, int B, int Ho,
+                           int Wo, int Cdy, int C1, int C2, int co_rows, int bco, ffa_stream_t stream);
 long long ffa_conv_wgrad_workspace_bytes(int dtype, int kh, int kw, int stride, int Co, int Ci, int B, int Ho, int Wo);
 int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* dw_oihw, int B, int Hi, int Wi, int Ci, int Ho,
                    int Wo, int Co, int Co_real, int Ci_real, int kh, int kw, int stride, int pad, int accumulate,

@@ -512,3 +512,33 @@ def test_wgrad_over_virtual_upsample_concat(cuda, dtype, c1, c2, cout, Hl, Wl):
     torch.cuda.synchronize()
     assert got is not None
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("c1,c2,cout,Hl,Wl", [
+    (128, 64, 64, 20, 24),    # 8x32 tiles, ragged
+    (64, 64, 32, 16, 16),
+    (32, 0, 16, 24, 16),      # no skip, 32-row blocks (4-channel runs)
+    (256, 128, 128, 6, 6),    # 16x16 tiles
+])
+def test_dgrad_with_fused_upsample_concat_backward(cuda, dtype, c1, c2, cout, Hl, Wl):
+    """ffa_conv2d_dgrad_upcat == dgrad conv + ffa_upsample_nearest2x_concat_bwd.  The pooled half sums four f32
+    accumulators before rounding once, the reference rounds dcat to storage precision first."""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(c1 + 5 * c2)
+    B = 3
+    cop = ops.pad_channels(cout)
+    dy = to_nhwc(torch.randn(B, cout, 2 * Hl, 2 * Wl, generator=g), dtype, cuda, cop)
+    w = (torch.randn(cout, c1 + c2, 3, 3, generator=g) / (cout * 9) ** 0.5).to(cuda)
+    pwt = ops.pack_conv_weight(w, dtype, 1, cop, transpose=True)
+    dcat = ops.conv2d(dy, pwt, 1, c1 + c2)
+    dlo_ref, dskip_ref = ops.upsample2x_concat_bwd(dcat, c1)
+    pair = ops.conv2d_dgrad_upcat(dy, pwt, c1, c2)
+    torch.cuda.synchronize()
+    assert pair is not None
+    dlo, dskip = pair
+    if c2:
+        assert torch.equal(dskip, dskip_ref)
+    tol = 1e-6 if dtype == torch.float32 else 2 ** -7
+    scale = dlo_ref.float().abs().max().item()
+    assert (dlo.float() - dlo_ref.float()).abs().max().item() <= tol * scale
