@@ -50,6 +50,11 @@ struct ConvArgs {
   float* stats;       // [npt][2][Co] per-tile channel sums / sums of squares of the stored output, or null
   const void* in2;    // UP kernels: the skip tensor [B][Hi][Wi][C2]; `in` is then the low-res map [B][Hi/2][Wi/2][C1]
   int c1_bytes;       // UP kernels: bytes of one pixel of `in` (C1 * sizeof(T)); the virtual input has Ci = C1 + C2
+  // BatchNorm-backward partials (bnx != null; needs stats): the tensor written is the gradient dy of
+  // y = relu(x * bn_sc + bn_sh); stats then receives per tile (sum g, sum g*x) with g = dy masked by y > 0
+  const void* bnx;    // the pre-normalisation tensor x, same shape / pitch as out
+  const float* bn_sc;
+  const float* bn_sh;
   void* out2;         // split epilogue (c1_out > 0): output channels >= c1_out go here, pixel pitch Co - c1_out
   int c1_out;         // split epilogue: output channels < c1_out are 2x2-sum-pooled into `out` [B][Ho/2][Wo/2][c1_out]
   const void* res;    // same layout as out, or null
@@ -571,11 +576,25 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
         }
         ffa_store8<T>(out + pix + c0, v);
         if (want_stats) {
+          if (a.bnx) {
+            float xv[8], sc[8], sh[8];
+            ffa_load8<T>(static_cast<const T*>(a.bnx) + pix + c0, xv);
+            ffa_load8<float>(a.bn_sc + c0, sc);
+            ffa_load8<float>(a.bn_sh + c0, sh);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float r = (EB == 2) ? ffa_bf16_bits_to_f32(ffa_f32_to_bf16_bits(v[i])) : v[i];
-            st[g * 8 + i] += r;
-            st[NCH + g * 8 + i] += r * r;
+            for (int i = 0; i < 8; ++i) {
+              const float r = (EB == 2) ? ffa_bf16_bits_to_f32(ffa_f32_to_bf16_bits(v[i])) : v[i];
+              const float gg = (xv[i] * sc[i] + sh[i]) > 0.f ? r : 0.f;  // same fma as the forward / apply kernels
+              st[g * 8 + i] += gg;
+              st[NCH + g * 8 + i] += gg * xv[i];
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const float r = (EB == 2) ? ffa_bf16_bits_to_f32(ffa_f32_to_bf16_bits(v[i])) : v[i];
+              st[g * 8 + i] += r;
+              st[NCH + g * 8 + i] += r * r;
+            }
           }
         }
       } else {
@@ -608,8 +627,15 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float r = (EB == 2) ? ffa_bf16_bits_to_f32(ffa_f32_to_bf16_bits(v[i])) : v[i];
-            st[g * 4 + i] += r;
-            st[NCH + g * 4 + i] += r * r;
+            if (a.bnx) {
+              const float xi = ffa_load_elem<T>(static_cast<const T*>(a.bnx) + pix + c0 + i);
+              const float gg = (xi * a.bn_sc[c0 + i] + a.bn_sh[c0 + i]) > 0.f ? r : 0.f;
+              st[g * 4 + i] += gg;
+              st[NCH + g * 4 + i] += gg * xi;
+            } else {
+              st[g * 4 + i] += r;
+              st[NCH + g * 4 + i] += r * r;
+            }
           }
         }
       }
@@ -761,7 +787,8 @@ extern "C" int ffa_conv_row_group(int kh) { return conv_rg(kh); }
 static int conv2d_impl(int dtype, const void* in, const void* w_packed, const float* bias, const void* residual,
                        void* out, float* stat_partials, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
                        int co_rows, int bco, int kh, int kw, int stride, int pad, int dil, int relu,
-                       hipStream_t stream, void* out2 = nullptr, int c1_out = 0) {
+                       hipStream_t stream, void* out2 = nullptr, int c1_out = 0, const void* bnx = nullptr,
+                       const float* bn_sc = nullptr, const float* bn_sh = nullptr) {
   FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "conv: bad dtype %d", dtype);
   FFA_REQUIRE(in && w_packed && out, "conv: null pointer");
   FFA_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "conv: bad dims");
@@ -790,6 +817,9 @@ static int conv2d_impl(int dtype, const void* in, const void* w_packed, const fl
   a.c1_bytes = 0;
   a.out2 = out2;
   a.c1_out = c1_out;
+  a.bnx = bnx;
+  a.bn_sc = bn_sc;
+  a.bn_sh = bn_sh;
   a.res = residual;
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci;
   a.Ho = Ho; a.Wo = Wo; a.Co = Co;
@@ -809,6 +839,19 @@ extern "C" int ffa_conv2d(int dtype, const void* in, const void* w_packed, const
                           int kh, int kw, int stride, int pad, int dil, int relu, hipStream_t stream) {
   return conv2d_impl(dtype, in, w_packed, bias, residual, out, nullptr, B, Hi, Wi, Ci, Ho, Wo, Co, co_rows, bco, kh, kw,
                      stride, pad, dil, relu, stream);
+}
+
+// ffa_conv2d whose output is the gradient dy of y = relu(bn(x)) (a dgrad convolution feeding a BatchNorm
+// backward): besides writing dy it leaves, per pixel tile, sum(g) and sum(g * x) with g = dy where
+// x * bn_scale + bn_shift > 0 else 0, in stat_partials[rows][2][Co] -- the reduction pass of the BatchNorm backward
+// comes out of the conv epilogue (ffa_bn_bwd_partials finishes the job).  bnx has the shape / pitch of out.
+extern "C" int ffa_conv2d_bnbwd(int dtype, const void* in, const void* w_packed, const void* residual, void* out,
+                                float* stat_partials, const void* bnx, const float* bn_scale, const float* bn_shift,
+                                int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int co_rows, int bco, int kh,
+                                int kw, int stride, int pad, int dil, hipStream_t stream) {
+  FFA_REQUIRE(stat_partials && bnx && bn_scale && bn_shift, "conv_bnbwd: null pointer");
+  return conv2d_impl(dtype, in, w_packed, nullptr, residual, out, stat_partials, B, Hi, Wi, Ci, Ho, Wo, Co, co_rows,
+                     bco, kh, kw, stride, pad, dil, 0, stream, nullptr, 0, bnx, bn_scale, bn_shift);
 }
 
 // Number of partial-statistics rows ffa_conv2d_stats writes for an output of B x Ho x Wo pixels (= pixel tiles).
@@ -862,6 +905,8 @@ extern "C" int ffa_conv2d_upcat(int dtype, const void* lo, const void* skip, con
   a.c1_bytes = C1 * eb;
   a.out2 = nullptr;
   a.c1_out = 0;
+  a.bnx = nullptr;
+  a.bn_sc = a.bn_sh = nullptr;
   a.w = w_packed;
   a.out = out;
   a.bias = bias;

@@ -427,10 +427,11 @@ extern "C" int ffa_bn_apply(int dtype, const void* x, const void* residual, void
 __global__ void __launch_bounds__(FFA_FIN_THREADS)
 bn_bwd_finalize_kernel(const float* __restrict__ ws, int nparts, int C, const float* __restrict__ gamma,
                        const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd, float inv_count,
-                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef, int raw_x = 0) {
   int c;
   double s, q;
   if (!reduce_partials(ws, nparts, C, c, s, q)) return;
+  if (raw_x) q = (q - (double)mean[c] * s) * (double)rstd[c];  // partials hold sum(g*x): sum(g*xhat) = rstd*(.. - mean*sum g)
   dbeta[c] = (float)s;
   dgamma[c] = (float)q;
   if (coef) {
@@ -518,6 +519,43 @@ extern "C" int ffa_bn_bwd(int dtype, const void* x, const void* dy, const void* 
                        relu);
   }
   return ffa_check_launch("bn_bwd");
+}
+
+// ffa_bn_bwd for y = relu(bn_train(x)) when the two reductions were already taken by the producer of dy
+// (ffa_conv2d_bnbwd): partials[nparts][2][C] = per-tile (sum g, sum g*x).  Finalize + apply only.
+extern "C" int ffa_bn_bwd_partials(int dtype, const void* x, const void* dy, const float* partials, long long nparts,
+                                   const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                   void* dx, float* dgamma, float* dbeta, long long npix, int C, void* workspace,
+                                   long long workspace_bytes, hipStream_t stream) {
+  FFA_REQUIRE(x && dy && partials && dx && mean && rstd && dgamma && dbeta && workspace, "bn_bwd_partials: null pointer");
+  FFA_REQUIRE(C % 8 == 0 && C >= 8 && C <= 8 * FFA_EW_THREADS && nparts > 0, "bn_bwd_partials: bad arguments");
+  if (workspace_bytes < ffa_bn_workspace_bytes(C)) {
+    ffa_set_error("bn_bwd_partials: workspace too small");
+    return FFA_ERR_WORKSPACE;
+  }
+  float* ws = static_cast<float*>(workspace);
+  float* coef = ws + (long long)FFA_MAX_PARTIALS * 2 * C;
+  const float* src = partials;
+  int n = (int)nparts;
+  if (nparts > FFA_MAX_PARTIALS) {
+    const int R = 64;
+    hipLaunchKernelGGL(partials_fold_kernel, dim3(ffa_cdiv(C, 8), R), dim3(FFA_FIN_THREADS), 0, stream, partials, nparts,
+                       C, R, ws);
+    src = ws;
+    n = R;
+  }
+  const long long nvec = npix * (C / 8);
+  const float inv_count = (float)(1.0 / (double)npix);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ffa_cdiv(C, 8)), dim3(FFA_FIN_THREADS), 0, stream, src, n, C, gamma, beta,
+                     mean, rstd, inv_count, dgamma, dbeta, coef, 1);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<ffa_bf16>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const ffa_bf16*)x, (const ffa_bf16*)dy, (const ffa_bf16*)nullptr, coef, (ffa_bf16*)dx,
+                       (ffa_bf16*)nullptr, nvec, C, 2);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream, (const float*)x,
+                       (const float*)dy, (const float*)nullptr, coef, (float*)dx, (float*)nullptr, nvec, C, 2);
+  return ffa_check_launch("bn_bwd_partials");
 }
 
 // ------------------------------------------------------------------------------------------------

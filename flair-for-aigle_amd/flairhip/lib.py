@@ -52,6 +52,8 @@ SIGNATURES = {
     "ffa_conv2d": (_i, [_i, _p, _p, _p, _p, _p] + [_i] * 15 + [_p]),
     "ffa_conv_stat_rows": (_ll, [_i, _i, _i]),
     "ffa_conv2d_stats": (_i, [_i, _p, _p, _p, _p, _p, _p] + [_i] * 15 + [_p]),
+    "ffa_conv2d_bnbwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 14 + [_p]),
+    "ffa_bn_bwd_partials": (_i, [_i, _p, _p, _p, _ll, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _p, _ll, _p]),
     "ffa_conv2d_dgrad_upcat": (_i, [_i, _p, _p, _p, _p] + [_i] * 8 + [_p]),
     "ffa_conv2d_upcat": (_i, [_i, _p, _p, _p, _p, _p, _p] + [_i] * 9 + [_p]),
     "ffa_conv_wgrad_workspace_bytes": (_ll, [_i] * 9),

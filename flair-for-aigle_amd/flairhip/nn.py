@@ -208,6 +208,57 @@ class _UpConvBnAct(torch.autograd.Function):
         return dlo, dskip, dw, dgamma, dbeta, None, None
 
 
+class _DecoderBlock(torch.autograd.Function):
+    """A whole U-Net DecoderBlock in training mode as one autograd node:
+        y = relu(bn_b(conv_b( relu(bn_a(conv_a( cat(nearest_x2(lo), skip) ))) )))
+    conv_a reads lo / skip directly (two-source kernels), and bn_a's backward reductions come out of conv_b's dgrad
+    epilogue -- which needs both layers in one node, the gradient tensor between them carries no side data."""
+
+    @staticmethod
+    def forward(ctx, lo, skip, wa, ga, ba, wb, gb, bb, blk):
+        ca, na, cb, nb = blk.conv1[0], blk.conv1[1], blk.conv2[0], blk.conv2[1]
+        xa, sca, sha, ma, ra = ops.conv2d_upcat_bn_stats(lo, skip, ca.packed(lo.dtype), ca.out_pitch, ga, ba,
+                                                         na.running_mean, na.running_var, na.momentum, na.eps)
+        na.note_batch()
+        ya = ops.bn_apply(xa, sca, sha, relu=True)
+        xb, scb, shb, mb, rb = ops.conv2d_bn_stats(ya, cb.packed(lo.dtype), cb.padding, cb.out_pitch, gb, bb,
+                                                   nb.running_mean, nb.running_var, nb.momentum, nb.eps)
+        nb.note_batch()
+        y = ops.bn_apply(xb, scb, shb, relu=True)
+        ctx.blk = blk
+        ctx.save_for_backward(lo, skip, xa, ya, xb, ga, ba, ma, ra, sca, sha, gb, bb, mb, rb)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lo, skip, xa, ya, xb, ga, ba, ma, ra, sca, sha, gb, bb, mb, rb = ctx.saved_tensors
+        blk = ctx.blk
+        ca, cb = blk.conv1[0], blk.conv2[0]
+        db_, _, dgb, dbb = ops.bn_bwd(xb, _as_nhwc_grad(dy), None, gb, bb, mb, rb, True, False)
+        dwb = ops.conv_wgrad(ya, db_, cb.out_channels, cb.in_channels, 3, 3, 1, 1) if ctx.needs_input_grad[5] else None
+        pbt = cb.packed(db_.dtype, transpose=True)
+        if ops.FUSED_BN_BWD:
+            dya, part, rows = ops.conv2d_bnbwd(db_, pbt, 1, ya.shape[-1], xa, sca, sha)
+            da, dga, dba = ops.bn_bwd_partials(xa, dya, part, rows, ga, ba, ma, ra)
+        else:
+            dya = ops.conv2d(db_, pbt, 1, ya.shape[-1])
+            da, _, dga, dba = ops.bn_bwd(xa, dya, None, ga, ba, ma, ra, True, False)
+        dlo = dskip = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            pat = ca.packed(da.dtype, transpose=True)
+            c1, c2 = lo.shape[-1], (0 if skip is None else skip.shape[-1])
+            pair = ops.conv2d_dgrad_upcat(da, pat, c1, c2)
+            if pair is None:
+                pair = ops.upsample2x_concat_bwd(ops.conv2d(da, pat, 1, ca.in_pitch), c1, skip_as_view=True)
+            dlo, dskip = pair
+        dwa = None
+        if ctx.needs_input_grad[2]:
+            dwa = ops.conv_wgrad_upcat(lo, skip, da, ca.out_channels)
+            if dwa is None:
+                raise RuntimeError("conv_wgrad_upcat refused a channel split that upcat_supported accepted")
+        return dlo, dskip, dwa, dga, dba, dwb, dgb, dbb, None
+
+
 class _BasicBlock(torch.autograd.Function):
     """One ResNet BasicBlock in training mode as a single autograd node:
         y = relu( bn2(conv2( relu(bn1(conv1(x))) )) + identity ),   identity = x  or  bn_d(conv_d(x)).
@@ -237,12 +288,12 @@ class _BasicBlock(torch.autograd.Function):
         n2.note_batch()
         y = ops.bn_apply(x2, sc2, sh2, residual=idt, relu=True)
         ctx.blk = blk
-        ctx.save_for_backward(x, x1, y1, x2, y, xd, g1, b1, m1, r1, g2, b2, m2, r2, gd, bd, md, rd)
+        ctx.save_for_backward(x, x1, y1, x2, y, xd, g1, b1, m1, r1, g2, b2, m2, r2, gd, bd, md, rd, sc1, sh1)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, x1, y1, x2, y, xd, g1, b1, m1, r1, g2, b2, m2, r2, gd, bd, md, rd = ctx.saved_tensors
+        x, x1, y1, x2, y, xd, g1, b1, m1, r1, g2, b2, m2, r2, gd, bd, md, rd, sc1, sh1 = ctx.saved_tensors
         blk = ctx.blk
         c1, c2 = blk.conv1, blk.conv2
         dy = _as_nhwc_grad(dy)
@@ -258,8 +309,14 @@ class _BasicBlock(torch.autograd.Function):
 
         d2, dres, dg2, db2 = ops.bn_bwd(x2, dy, y, g2, b2, m2, r2, True, True)
         dw2 = wgrad(c2, y1, d2) if ctx.needs_input_grad[4] else None
-        dy1 = dgrad(c2, d2, y1)
-        d1, _, dg1, db1 = ops.bn_bwd(x1, dy1, None, g1, b1, m1, r1, True, False)
+        if ops.FUSED_BN_BWD:
+            # bn1's backward reductions come out of conv2's dgrad epilogue (one pass over x1 and dy1 fewer)
+            dy1, part, rows = ops.conv2d_bnbwd(d2, c2.packed(d2.dtype, transpose=True), c2.kernel_size - 1 - c2.padding,
+                                               y1.shape[-1], x1, sc1, sh1)
+            d1, dg1, db1 = ops.bn_bwd_partials(x1, dy1, part, rows, g1, b1, m1, r1)
+        else:
+            dy1 = dgrad(c2, d2, y1)
+            d1, _, dg1, db1 = ops.bn_bwd(x1, dy1, None, g1, b1, m1, r1, True, False)
         dw1 = wgrad(c1, x, d1) if ctx.needs_input_grad[1] else None
         dwd = dgd = dbd = None
         if blk.downsample is not None:
@@ -470,6 +527,18 @@ def up_conv_bn_act(lo, skip, conv: HipConv2d, bn: HipBatchNorm2d):
         if y is not None:
             return y
     return conv_bn_act(up_concat(lo, skip), conv, bn, relu=True)
+
+
+def decoder_block(lo, skip, blk):
+    """Training-mode forward of a DecoderBlock module (conv1 = [conv, bn], conv2 = [conv, bn]); None when the channel
+    split needs the explicit concat (the caller then chains up_conv_bn_act / conv_bn_act)."""
+    ca, cb = blk.conv1[0], blk.conv2[0]
+    c1, c2 = lo.shape[-1], (0 if skip is None else skip.shape[-1])
+    if not (ca.kernel_size == 3 and ca.stride == 1 and ca.padding == 1 and ca.in_channels == c1 + c2 and
+            cb.kernel_size == 3 and cb.stride == 1 and cb.padding == 1 and ops.upcat_supported(c1, c2, lo.dtype)):
+        return None
+    return _DecoderBlock.apply(lo, skip, ca.weight, blk.conv1[1].weight, blk.conv1[1].bias, cb.weight,
+                               blk.conv2[1].weight, blk.conv2[1].bias, blk)
 
 
 def basic_block(x, blk):

@@ -195,6 +195,50 @@ def conv2d_upcat(lo: torch.Tensor, skip: Optional[torch.Tensor], w: PackedWeight
     return out
 
 
+# BatchNorm-backward reductions from the dgrad epilogue (ffa_conv2d_bnbwd).  Measured on MI355X, same session: 16.31 vs
+# 16.24 ms/step without -- the epilogue's per-lane 16-byte reads of x (one cache line per lane) cost what the saved
+# reduction pass gained -- so it stays OFF by default; FFA_FUSED_BN_BWD=1 turns it on (covered by the kernel tests).
+FUSED_BN_BWD = os.environ.get("FFA_FUSED_BN_BWD", "0") == "1"
+
+
+def conv2d_bnbwd(x: torch.Tensor, w: PackedWeight, pad: int, out_channels: int, bnx: torch.Tensor,
+                 bn_scale: torch.Tensor, bn_shift: torch.Tensor, residual: Optional[torch.Tensor] = None, dil: int = 1,
+                 out_hw: Optional[Tuple[int, int]] = None):
+    """A (dgrad) convolution whose output dy is the gradient of relu(bn(bnx)): -> (dy, partials, rows) with the
+    BatchNorm-backward reductions sum(g), sum(g*bnx) taken in the conv epilogue (see bn_bwd_partials)."""
+    lib = _l.load()
+    _chk_nhwc(x, "conv input")
+    B, Hi, Wi, Ci = x.shape
+    if out_hw is None:
+        hv, wv = (Hi * 2, Wi * 2) if dil == 2 else (Hi, Wi)
+        out_hw = (conv_out_size(hv, w.kh, w.stride, pad), conv_out_size(wv, w.kw, w.stride, pad))
+    Ho, Wo = out_hw
+    if tuple(bnx.shape) != (B, Ho, Wo, out_channels) or bnx.dtype != x.dtype or not bnx.is_contiguous():
+        raise ValueError("conv2d_bnbwd: bnx must have the shape, pitch and dtype of the output")
+    out = torch.empty((B, Ho, Wo, out_channels), dtype=x.dtype, device=x.device)
+    rows = conv_stat_rows(B, Ho, Wo)
+    part = workspace(rows * 2 * out_channels * 4, x.device, "bnpart").view(torch.float32)
+    _l.check(lib.ffa_conv2d_bnbwd(_dt(x), x.data_ptr(), w.data.data_ptr(), _ptr(residual), out.data_ptr(),
+                                  part.data_ptr(), bnx.data_ptr(), bn_scale.data_ptr(), bn_shift.data_ptr(), B, Hi, Wi,
+                                  Ci, Ho, Wo, out_channels, w.rows, w.bco, w.kh, w.kw, w.stride, pad, dil, _stream()),
+             "conv2d_bnbwd")
+    return out, part, rows
+
+
+def bn_bwd_partials(x: torch.Tensor, dy: torch.Tensor, part: torch.Tensor, rows: int, gamma, beta, mean, rstd):
+    """BatchNorm (+ReLU, mask from x) backward from the partial sums of conv2d_bnbwd -> (dx, dgamma, dbeta)"""
+    lib = _l.load()
+    C_ = x.shape[-1]
+    dx = torch.empty_like(x)
+    dgb = torch.empty((2, C_), dtype=torch.float32, device=x.device)
+    ws = workspace(lib.ffa_bn_workspace_bytes(C_), x.device, "bn")
+    _l.check(lib.ffa_bn_bwd_partials(_dt(x), x.data_ptr(), dy.data_ptr(), part.data_ptr(), rows, _ptr(gamma), _ptr(beta),
+                                     mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dgb[0].data_ptr(),
+                                     dgb[1].data_ptr(), x.numel() // C_, C_, ws.data_ptr(), ws.numel(), _stream()),
+             "bn_bwd_partials")
+    return dx, dgb[0], dgb[1]
+
+
 def conv2d_dgrad_upcat(dy: torch.Tensor, wt: PackedWeight, c1: int, c2: int):
     """Input gradient of conv2d_upcat -> (dlo [B,H/2,W/2,c1], dskip [B,H,W,c2] or None), or None when the channel
     split is not supported (the caller then runs the plain dgrad + upsample2x_concat_bwd)."""

@@ -81,6 +81,10 @@ class DecoderBlock(nn.Module):
         self.conv2 = nn.Sequential(hnn.HipConv2d(cout, cout, 3, 1, 1), hnn.HipBatchNorm2d(cout))
 
     def forward(self, x, skip: Optional[torch.Tensor] = None):
+        if self.training and torch.is_grad_enabled():
+            y = hnn.decoder_block(x, skip, self)  # one autograd node (two-source conv1, fused BN-backward sums)
+            if y is not None:
+                return y
         # nearest x2 + concat + conv1 + BN + ReLU; the concatenated tensor is only materialised when the two-source
         # kernels do not take the channel split
         x = hnn.up_conv_bn_act(x, skip, self.conv1[0], self.conv1[1])

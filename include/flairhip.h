@@ -74,6 +74,14 @@ int ffa_conv2d_stats(int dtype, const void* in, const void* w_packed, const floa
                      int co_rows, int bco, int kh, int kw, int stride, int pad, int dil, int relu,
                      ffa_stream_t stream);
 
+/* ffa_conv2d whose output is the gradient dy of y = relu(bn_train(x)) -- a dgrad convolution feeding a BatchNorm
+ * backward: also leaves per tile sum(g), sum(g*x), g = dy masked by x*bn_scale + bn_shift > 0, in
+ * stat_partials[rows][2][Co], so that ffa_bn_bwd_partials can skip the reduction pass of ffa_bn_bwd. */
+int ffa_conv2d_bnbwd(int dtype, const void* in, const void* w_packed, const void* residual, void* out,
+                     float* stat_partials, const void* bnx, const float* bn_scale, const float* bn_shift, int B, int Hi,
+                     int Wi, int Ci, int Ho, int Wo, int Co, int co_rows, int bco, int kh, int kw, int stride, int pad,
+                     int dil, ffa_stream_t stream);
+
 /* 3x3 stride-1 pad-1 convolution over the virtual tensor cat(nearest_x2(lo), skip) -- what smp's DecoderBlock builds
  * with F.interpolate(scale_factor=2, mode="nearest") + torch.cat before its first conv (reached from
  * flair_model.py:417-419) -- without writing it: lo [B][Hl][Wl][C1], skip [B][2Hl][2Wl][C2] or null.
@@ -119,6 +127,11 @@ int ffa_bn_apply(int dtype, const void* x, const void* residual, void* y, const 
 int ffa_bn_bwd(int dtype, const void* x, const void* dy, const void* y, const float* gamma, const float* beta,
                const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, long long npix,
                int C, int relu, void* workspace, long long workspace_bytes, ffa_stream_t stream);
+/* ffa_bn_bwd (ReLU mask recomputed from x) when sum(g) / sum(g*x) per tile already exist (ffa_conv2d_bnbwd) */
+int ffa_bn_bwd_partials(int dtype, const void* x, const void* dy, const float* partials, long long nparts,
+                        const float* gamma, const float* beta, const float* mean, const float* rstd, void* dx,
+                        float* dgamma, float* dbeta, long long npix, int C, void* workspace, long long workspace_bytes,
+                        ffa_stream_t stream);
 int ffa_channel_sums(int dtype, const void* x, long long npix, int C, float* sum_out, float* sumsq_out,
                      void* workspace, long long workspace_bytes, ffa_stream_t stream);
 int ffa_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int C,

@@ -542,3 +542,31 @@ def test_dgrad_with_fused_upsample_concat_backward(cuda, dtype, c1, c2, cout, Hl
     tol = 1e-6 if dtype == torch.float32 else 2 ** -7
     scale = dlo_ref.float().abs().max().item()
     assert (dlo.float() - dlo_ref.float()).abs().max().item() <= tol * scale
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 40, 72), (128, 32, 24, 40), (16, 16, 300, 48), (256, 128, 6, 6)])
+def test_bn_backward_reductions_from_dgrad_epilogue(cuda, dtype, cin, cout, H, W):
+    """ffa_conv2d_bnbwd + ffa_bn_bwd_partials == ffa_conv2d + ffa_bn_bwd (mask recomputed from x)"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(cin + 3 * cout)
+    B = 9 if H * W > 10000 else 3
+    cip, cop = ops.pad_channels(cin), ops.pad_channels(cout)
+    d2 = to_nhwc(torch.randn(B, cin, H, W, generator=g), dtype, cuda, cip)          # incoming gradient
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(cuda)      # acts as the dgrad operand
+    pw = ops.pack_conv_weight(w, dtype, 1, cip)
+    x1 = to_nhwc(torch.randn(B, cout, H, W, generator=g), dtype, cuda, cop)          # pre-norm tensor of the BN
+    gamma = (torch.rand(cop, generator=g) + 0.5).to(cuda)
+    beta = (torch.randn(cop, generator=g) * 0.3).to(cuda)
+    rm, rv = torch.zeros(cop, device=cuda), torch.ones(cop, device=cuda)
+    scale, shift, mean, rstd = ops.bn_stats(x1, gamma, beta, rm, rv, 0.1, 1e-5)
+    dy_ref = ops.conv2d(d2, pw, 1, cop)
+    dx_ref, _, dg_ref, db_ref = ops.bn_bwd(x1, dy_ref, None, gamma, beta, mean, rstd, True, False)
+    dy, part, rows = ops.conv2d_bnbwd(d2, pw, 1, cop, x1, scale, shift)
+    dx, dg, db = ops.bn_bwd_partials(x1, dy, part, rows, gamma, beta, mean, rstd)
+    torch.cuda.synchronize()
+    assert torch.equal(dy, dy_ref)
+    assert torch.allclose(db[:cout], db_ref[:cout], rtol=1e-4, atol=1e-4 * float(db_ref.abs().max()))
+    assert torch.allclose(dg[:cout], dg_ref[:cout], rtol=1e-4, atol=1e-4 * float(dg_ref.abs().max()))
+    tol = 1e-5 if dtype == torch.float32 else 2 ** -7
+    assert (dx.float() - dx_ref.float()).abs().max().item() <= tol * max(1.0, dx_ref.float().abs().max().item())
