@@ -165,11 +165,13 @@ def test_fused_decoder_prologue_and_bn_statistics_equal_the_unfused_path(cuda, m
         w = dict(task.model.named_parameters())[f"main_decoders.{TASK}.seg_model.decoder.blocks.1.conv1.0.weight"]
         return loss.detach().clone(), w.grad.clone()
 
+    monkeypatch.setattr(ops, "FUSED_BN_BWD", True)  # off by default (measured neutral): exercised here
     fused_eval, _ = run(False)
     state = {k: v.clone() for k, v in task.state_dict().items()}
     fused_loss, fused_grad = run(True)
     monkeypatch.setattr(ops, "FUSED_UPCAT", False)
     monkeypatch.setattr(ops, "FUSED_BN_STATS", False)
+    monkeypatch.setattr(ops, "FUSED_BN_BWD", False)
     task.load_state_dict(state)
     plain_eval, _ = run(False)
     plain_loss, plain_grad = run(True)
