@@ -84,7 +84,40 @@ class KernelTimer:
             timer.records.append((sym, flops, s, e))
             return r
 
+        orig_dgrad_up, orig_up = ops.conv2d_dgrad_upcat, ops.conv2d_upcat
+
+        def conv2d_dgrad_upcat(dy, wt, c1, c2):
+            # same kernel instantiation as the plain 3x3 dgrad (the fused 2x2 pooling lives in its epilogue)
+            if not timer.enabled:
+                return orig_dgrad_up(dy, wt, c1, c2)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_dgrad_up(dy, wt, c1, c2)
+            e.record()
+            if r is not None:
+                B, H, W = dy.shape[0], dy.shape[1], dy.shape[2]
+                dt = "bf16" if dy.dtype == torch.bfloat16 else "f32"
+                sym = f"conv_igemm_kernel<{dt},3x3,s1,bco{wt.bco},{'8x32' if W >= 32 else '16x16'}>"
+                timer.records.append((sym, 2.0 * B * H * W * wt.rows_real * wt.ch_real * 9, s, e))
+            return r
+
+        def conv2d_upcat(lo, skip, w, out_channels, *a, **kw):
+            # the two-source instantiation (template flag UP): its own symbol in rocprofv3 as well
+            if not timer.enabled:
+                return orig_up(lo, skip, w, out_channels, *a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = orig_up(lo, skip, w, out_channels, *a, **kw)
+            e.record()
+            if y is not None:
+                B, H, W = y.shape[0], y.shape[1], y.shape[2]
+                dt = "bf16" if lo.dtype == torch.bfloat16 else "f32"
+                sym = f"conv_igemm_kernel<{dt},3x3,s1,bco{w.bco},{'8x32' if W >= 32 else '16x16'},up>"
+                timer.records.append((sym, 2.0 * B * H * W * w.rows_real * w.ch_real * 9, s, e))
+            return y
+
         ops.conv2d, ops.conv_wgrad = conv2d, conv_wgrad
+        ops.conv2d_dgrad_upcat, ops.conv2d_upcat = conv2d_dgrad_upcat, conv2d_upcat
 
     def summary(self):
         agg = defaultdict(lambda: [0.0, 0.0, 0])
@@ -115,6 +148,8 @@ def pmc_traffic(symbol: str):
         if kind == "conv_igemm_kernel":
             th, tw = (m.group(8) or "8x32").split("x")
             if f", {m.group(5)}, " not in name or f", {th}, {tw}," not in name:
+                continue
+            if ("true>" in name) != symbol.endswith(",up>"):  # two-source instantiation (template flag UP)
                 continue
         else:
             if f", {m.group(6)}, {m.group(7)}," not in name:
