@@ -73,6 +73,43 @@ extern "C" int ffa_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, i
   return ffa_check_launch("nchw_to_nhwc");
 }
 
+// uint8 NCHW raster tiles -> normalised NHWC compute tensor in one pass: dst = (src - mean[c]) / std[c] (the 'custom'
+// normalisation of flair_hub/data/utils_data/norm.py:37-44; 'scaling' is mean 0, std 255).  The zonal loop then ships
+// 1 byte per input sample over PCIe instead of 4 and does no per-tile float work on the host.
+template <typename T>
+__global__ void u8_nchw_to_nhwc_kernel(const uint8_t* __restrict__ src, T* __restrict__ dst, int B, int C, int H, int W,
+                                       int Cp, const float* __restrict__ mean, const float* __restrict__ stdv) {
+  const int groups = Cp / 8;
+  const long long hw = (long long)H * W;
+  const long long total = (long long)B * hw * groups;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long pix = i % ((long long)B * hw);
+    const int g = (int)(i / ((long long)B * hw));
+    const long long b = pix / hw, p = pix % hw;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = g * 8 + e;
+      v[e] = (c < C) ? ((float)src[(b * C + c) * hw + p] - mean[c]) / stdv[c] : 0.f;
+    }
+    ffa_store8<T>(dst + pix * Cp + g * 8, v);
+  }
+}
+
+extern "C" int ffa_u8_nchw_to_nhwc(int dtype, const uint8_t* src, void* dst, int B, int C, int H, int W, int Cp,
+                                   const float* mean, const float* stdv, hipStream_t stream) {
+  FFA_REQUIRE(src && dst && mean && stdv && Cp % 8 == 0 && Cp >= C, "u8_nchw_to_nhwc: bad arguments (C=%d Cp=%d)", C, Cp);
+  const long long items = (long long)B * H * W * (Cp / 8);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(u8_nchw_to_nhwc_kernel<ffa_bf16>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream, src,
+                       (ffa_bf16*)dst, B, C, H, W, Cp, mean, stdv);
+  else
+    hipLaunchKernelGGL(u8_nchw_to_nhwc_kernel<float>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream, src,
+                       (float*)dst, B, C, H, W, Cp, mean, stdv);
+  return ffa_check_launch("u8_nchw_to_nhwc");
+}
+
 extern "C" int ffa_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H, int W, int Cp,
                                 hipStream_t stream) {
   FFA_REQUIRE(src && dst && Cp >= C, "nhwc_to_nchw: bad arguments");

@@ -40,7 +40,8 @@ def normalize_array(img: np.ndarray, norm_type, means, stds) -> np.ndarray:
 
 class MultiModalSlicedDataset(Dataset):
     def __init__(self, dataframe, modality_cfgs: Dict[str, Dict[str, Any]], patch_size_dict: Dict[str, int],
-                 ref_date_str: str, modalities_config: Dict[str, Any], reference_batch_schema: bool = False) -> None:
+                 ref_date_str: str, modalities_config: Dict[str, Any], reference_batch_schema: bool = False,
+                 device_normalize: bool = False) -> None:
         if any(m.endswith("_TS") for m in modality_cfgs):
             raise NotImplementedError("time-series modalities are not implemented on libflairhip yet")
         self.df = dataframe
@@ -49,6 +50,9 @@ class MultiModalSlicedDataset(Dataset):
         self.patch_sizes = patch_size_dict
         self.ref_date_str = ref_date_str
         self.reference_batch_schema = reference_batch_schema
+        # uint8 rasters with 'custom' / 'scaling' normalisation: hand the raw bytes over and let the layout kernel on
+        # the device normalise (ffa_u8_nchw_to_nhwc): a quarter of the PCIe bytes, no per-tile float work here
+        self.device_normalize = device_normalize and not reference_batch_schema
         self.readers = {m: open_raster(cfg["input_img_path"]) for m, cfg in modality_cfgs.items()}
 
     def __len__(self) -> int:
@@ -68,6 +72,19 @@ class MultiModalSlicedDataset(Dataset):
         return reader.read(indexes=cfg["channels"], window=window, out_shape=(len(cfg["channels"]), patch_size,
                            patch_size), resampling=Resampling.bilinear, boundless=True, fill_value=0)
 
+    def norm_vectors(self, mod: str):
+        """(mean, std) per channel of the normalisation the device applies to uint8 tiles of ``mod``, or None"""
+        cfg = self.modalities[mod]
+        ncfg = cfg.get("normalization") or {}
+        n = len(cfg["channels"])
+        if ncfg.get("type") == "custom":
+            if len(ncfg["means"]) != len(ncfg["stds"]):
+                raise ValueError("If using 'custom', the provided means and stds must have the same length.")
+            return np.asarray(ncfg["means"][:n], np.float32), np.asarray(ncfg["stds"][:n], np.float32)
+        if ncfg.get("type") == "scaling":
+            return np.zeros(n, np.float32), np.full(n, 255.0, np.float32)
+        return None
+
     def __getitem__(self, idx: int) -> Dict[str, torch.Tensor]:
         row = self.df.iloc[idx]
         bounds = self._tile_box(row)
@@ -75,6 +92,9 @@ class MultiModalSlicedDataset(Dataset):
         for mod, cfg in self.modalities.items():
             patch = self._load_patch(self.readers[mod], bounds, cfg, self.patch_sizes[mod])
             ncfg = cfg.get("normalization", {})
+            if self.device_normalize and patch.dtype == np.uint8 and self.norm_vectors(mod) is not None:
+                out[mod] = torch.from_numpy(np.ascontiguousarray(patch))
+                continue
             norm = normalize_array(patch, ncfg.get("type"), ncfg.get("means"), ncfg.get("stds")) if ncfg else patch
             out[mod] = torch.tensor(np.ascontiguousarray(norm), dtype=torch.float32)
             if self.reference_batch_schema:

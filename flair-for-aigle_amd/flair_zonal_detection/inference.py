@@ -111,7 +111,8 @@ def prep_dataset(config: Dict, tiles_gdf, patch_sizes: Dict[str, int]) -> MultiM
     config["labels_configs"] = {t["name"]: {"value_name": t["class_names"]} for t in config["tasks"] if t["active"]}
     return MultiModalSlicedDataset(dataframe=tiles_gdf, modality_cfgs={m: config["modalities"][m] for m in active},
                                    patch_size_dict=patch_sizes, ref_date_str=config.get("multitemp_model_ref_date", "05-15"),
-                                   modalities_config=config)
+                                   modalities_config=config,
+                                   device_normalize=bool(config.get("device_normalize", True)))
 
 
 def init_outputs(config: Dict, ref_img, i=None) -> Tuple[Dict[str, object], Dict[str, str]]:
@@ -177,8 +178,20 @@ def inference_and_write(model: torch.nn.Module, dataloader: DataLoader, tiles_gd
     img_bounds = tuple(ref_img.bounds)  # (left, bottom, right, top)
     keep = tile_size - 2 * margin
 
+    # uint8 tiles (dataset with device_normalize): the per-channel (mean, std) ride along once per modality
+    norms = {}
+    ds = getattr(dataloader, "dataset", None)
+    if getattr(ds, "device_normalize", False):
+        for mod in ds.modalities:
+            nv = ds.norm_vectors(mod)
+            if nv is not None:
+                norms[mod + "_NORM"] = torch.tensor(np.stack(nv), dtype=torch.float32, device=device)
+
     for batch in dataloader:
         inputs = {k: v.to(device, non_blocking=True) for k, v in batch.items() if k != "index" and torch.is_tensor(v)}
+        for k, v in norms.items():
+            if inputs.get(k[:-5]) is not None and inputs[k[:-5]].dtype == torch.uint8:
+                inputs[k] = v
         indices = batch["index"].cpu().numpy().flatten()
         rows = tiles_gdf.iloc[indices]
         logits_tasks, _ = model(inputs)
@@ -217,7 +230,8 @@ def run_inference(config_path, ref_raster=None, geozone=None) -> Dict[str, objec
     patch_sizes = compute_patch_sizes(config)
     model = build_inference_model(config, patch_sizes).to(config["device"])
     dataset = prep_dataset(config, tiles, patch_sizes)
-    loader = DataLoader(dataset, batch_size=config.get("batch_size", 8), num_workers=config.get("num_worker", 0))
+    loader = DataLoader(dataset, batch_size=config.get("batch_size", 8), num_workers=config.get("num_worker", 0),
+                        pin_memory=True)
     outputs, _ = init_outputs(config, ref_img)
     inference_and_write(model, loader, tiles, config, outputs, ref_img)
     logger.info("zonal inference of %d tiles took %.1f s", len(tiles), time.time() - t0)

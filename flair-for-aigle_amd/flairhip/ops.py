@@ -477,6 +477,22 @@ def nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, cp: Optional[int] = None) 
     return out
 
 
+def u8_nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, mean: torch.Tensor, std: torch.Tensor,
+                    cp: Optional[int] = None) -> torch.Tensor:
+    """uint8 [B,C,H,W] -> NHWC compute tensor holding (x - mean[c]) / std[c]; mean / std f32 device vectors [C]"""
+    lib = _l.load()
+    if x.dtype != torch.uint8 or x.ndim != 4 or not x.is_contiguous():
+        raise ValueError("u8_nchw_to_nhwc: contiguous uint8 [B,C,H,W] expected")
+    B, C_, H, W = x.shape
+    if mean.numel() < C_ or std.numel() < C_ or mean.dtype != torch.float32 or std.dtype != torch.float32:
+        raise ValueError("u8_nchw_to_nhwc: mean / std must be f32 vectors with one entry per channel")
+    cp = pad_channels(C_) if cp is None else cp
+    out = torch.empty((B, H, W, cp), dtype=dtype, device=x.device)
+    _l.check(lib.ffa_u8_nchw_to_nhwc(_dtype_id(dtype), x.data_ptr(), out.data_ptr(), B, C_, H, W, cp, mean.data_ptr(),
+                                     std.data_ptr(), _stream()), "u8_nchw_to_nhwc")
+    return out
+
+
 def nhwc_to_nchw(x: torch.Tensor, channels: int) -> torch.Tensor:
     lib = _l.load()
     _chk_nhwc(x, "nhwc_to_nchw input")

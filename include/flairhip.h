@@ -142,6 +142,10 @@ int ffa_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx
 /* ---- layout hand-over at the model boundary (batch dict tensors are NCHW f32:
  *      flair_hub/data/dataloader.py:105-257, flair_zonal_detection/dataset.py:174-209) -------------- */
 int ffa_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H, int W, int Cp, ffa_stream_t stream);
+/* uint8 NCHW raster tiles -> (x - mean[c]) / std[c] as NHWC compute tensor (the zonal dataset's normalisation,
+ * flair_hub/data/utils_data/norm.py:37-44 reached from flair_zonal_detection/dataset.py:174-209, done on the device) */
+int ffa_u8_nchw_to_nhwc(int dtype, const uint8_t* src, void* dst, int B, int C, int H, int W, int Cp,
+                        const float* mean, const float* stdv, ffa_stream_t stream);
 int ffa_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H, int W, int Cp, ffa_stream_t stream);
 
 /* ---- decoder resampling (smp DecoderBlock nearest x2 + cat; flair_model.py:318-327 interpolate_map) */

@@ -570,3 +570,20 @@ def test_bn_backward_reductions_from_dgrad_epilogue(cuda, dtype, cin, cout, H, W
     assert torch.allclose(dg[:cout], dg_ref[:cout], rtol=1e-4, atol=1e-4 * float(dg_ref.abs().max()))
     tol = 1e-5 if dtype == torch.float32 else 2 ** -7
     assert (dx.float() - dx_ref.float()).abs().max().item() <= tol * max(1.0, dx_ref.float().abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_u8_tiles_normalised_by_the_layout_kernel(cuda, dtype):
+    """ffa_u8_nchw_to_nhwc == the dataset's (x - mean) / std (norm.py:37-44) followed by the f32 layout kernel"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(8)
+    x = torch.randint(0, 256, (2, 5, 24, 40), generator=g, dtype=torch.uint8)
+    mean = torch.tensor([105.66, 111.35, 102.18, 90.0, 33.3])
+    std = torch.tensor([52.23, 45.62, 44.30, 60.1, 20.0])
+    ref = ((x.double() - mean.double()[None, :, None, None]) / std.double()[None, :, None, None]).float()
+    want = ops.nchw_to_nhwc(ref.to(cuda), dtype, 16)
+    got = ops.u8_nchw_to_nhwc(x.to(cuda), dtype, mean.to(cuda), std.to(cuda), 16)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape and float(got[..., 5:].float().abs().max()) == 0.0
+    tol = 1e-6 if dtype == torch.float32 else 2 ** -8
+    assert (got.float() - want.float()).abs().max().item() <= tol * 5.0

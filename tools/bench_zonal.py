@@ -1,0 +1,103 @@
+#!/usr/bin/env python
+"""Zonal inference throughput on a synthetic in-memory raster.
+
+  python tools/bench_zonal.py [--size 6048] [--batch 8]
+
+Reports (a) the model forward alone (eval mode: BatchNorm folded into the conv operands, bias / ReLU / decoder
+upsample+concat in conv epilogues / prologues) at the loop's batch size and at 32, and (b) the whole
+run_inference loop: slicing, windowed reads + normalisation (numpy, host), H2D, forward, fused margin-crop + argmax,
+D2H of 1 byte per kept pixel, window placement, writes into the in-memory output raster.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flair-for-aigle_amd"))
+
+import numpy as np
+import torch
+import yaml
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=6048, help="raster height = width in pixels")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--precision", default="bf16")
+    args = ap.parse_args()
+    from flairhip.configs import unet_resnet34_config
+    from flair_hub.models.flair_model import FLAIR_HUB_Model
+    from flair_zonal_detection.inference import run_inference
+    from flair_zonal_detection.raster import ArrayRaster
+
+    dev = torch.device("cuda:0")
+    MOD, TASK = "AERIAL_RGBI", "AERIAL_LABEL-COSIA"
+    # (a) forward alone
+    cfg = unet_resnet34_config(in_channels=5, precision=args.precision)
+    model = FLAIR_HUB_Model(cfg, {MOD: 512}).to(dev).eval()
+    for B in (args.batch, 32):
+        x = torch.randn(B, 5, 512, 512, device=dev)
+        with torch.no_grad():
+            for _ in range(3):
+                model({MOD: x})
+            torch.cuda.synchronize()
+            t0 = time.time()
+            n = 10
+            for _ in range(n):
+                model({MOD: x})
+            torch.cuda.synchronize()
+        dt = (time.time() - t0) / n
+        print(f"forward only, batch {B:2d}: {dt * 1e3:7.2f} ms/batch = {B / dt:8.1f} tiles/s")
+
+    # (b) the zonal loop
+    g = np.random.default_rng(0)
+    H = W = args.size
+    img = g.integers(0, 255, (5, H, W), dtype=np.uint8)
+    ras = ArrayRaster(img, 651000.0, 6865000.0, 0.2)
+    zc = yaml.safe_load(open(os.path.join(ROOT, "tests", "golden", "zonal_config.yaml")))
+    zc.update({"output_path": "/tmp", "output_name": "bench_zonal", "img_pixels_detection": 512, "margin": 40,
+               "output_px_meters": 0.2, "output_type": "argmax", "batch_size": args.batch, "num_worker": 0,
+               "hardware": {"precision": args.precision}, "model_weights": "/tmp/bench_zonal_weights.ckpt",
+               "monotemp_arch": "resnet34-unet"})
+    torch.save({"state_dict": {"model." + k: v.cpu() for k, v in model.state_dict().items()}}, zc["model_weights"])
+    zc["modalities"][MOD].update({"input_img_path": ras, "channels": [1, 2, 3, 4, 5],
+                                  "normalization": {"type": "custom", "means": [110.0] * 5, "stds": [50.0] * 5}})
+    zc["tasks"] = [{"name": TASK, "active": True, "class_names": {i: f"c{i}" for i in range(19)}}]
+    t0 = time.time()
+    out = run_inference(zc)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    ntiles = ((H + 80 + 431) // 432) ** 2
+    print(f"run_inference on {H}x{W} px ({ntiles} tiles of 512, batch {args.batch}): {dt:.2f} s = {ntiles / dt:.1f} tiles/s, "
+          f"{H * W / dt / 1e6:.1f} Mpx/s; output {out[TASK].data.shape}")
+
+    # the same run split into its stages (second pass: kernels and workspaces are warm)
+    from torch.utils.data import DataLoader
+    from flair_zonal_detection import inference as zi
+    from flair_zonal_detection.model_utils import build_inference_model, compute_patch_sizes
+    from flair_zonal_detection.slicing import generate_patches_from_reference
+    t = [time.time()]
+    cfg2 = zi.prep_config(zc)
+    tiles = generate_patches_from_reference(cfg2, ras, None)
+    t.append(time.time())
+    sizes = compute_patch_sizes(cfg2)
+    mdl = build_inference_model(cfg2, sizes).to(cfg2["device"])
+    t.append(time.time())
+    ds = zi.prep_dataset(cfg2, tiles, sizes)
+    loader = DataLoader(ds, batch_size=args.batch, num_workers=0, pin_memory=True)
+    outputs, _ = zi.init_outputs(cfg2, ras)
+    t.append(time.time())
+    zi.inference_and_write(mdl, loader, tiles, cfg2, outputs, ras)
+    torch.cuda.synchronize()
+    t.append(time.time())
+    names = ["config + slicing", "model build + checkpoint", "dataset + output rasters", "tile loop"]
+    print("  stages: " + ", ".join(f"{n} {b - a:.2f} s" for n, a, b in zip(names, t, t[1:])) +
+          f"  -> tile loop alone {len(tiles) / (t[4] - t[3]):.0f} tiles/s")
+
+
+if __name__ == "__main__":
+    main()
