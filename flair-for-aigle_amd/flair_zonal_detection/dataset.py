@@ -106,3 +106,53 @@ class MultiModalSlicedDataset(Dataset):
                 k = len(self.modalities_config["labels_configs"][task]["value_name"])
                 out[task] = torch.zeros((k, ref_size, ref_size), dtype=torch.float32)
         return out
+
+
+class TileBatcher:
+    """Batches of raw uint8 tiles for the zonal loop, written by the raster reader straight into reused pinned host
+    buffers: no per-tile tensor, no collate copy, no pin copy (torch's default DataLoader path spent 60 % of the
+    loop's wall time in torch.stack and pandas row lookups).  Needs a dataset in device_normalize mode whose
+    rasters read uint8 and accept ``read_bounds(..., out=)``; use ``TileBatcher.supports(dataset)``.
+
+    Yields the same dict a DataLoader over the dataset would: {'<MOD>': uint8 [n,C,P,P], 'index': int64 [n,1]}.
+    Two buffers per modality alternate, so a batch stays valid until the batch after next is requested."""
+
+    def __init__(self, dataset: MultiModalSlicedDataset, batch_size: int):
+        if not self.supports(dataset):
+            raise ValueError("TileBatcher needs device_normalize uint8 rasters with read_bounds(..., out=)")
+        self.ds = self.dataset = dataset
+        self.bs = self.batch_size = int(batch_size)
+        self.boxes = [dataset._tile_box(dataset.df.iloc[i]) for i in range(len(dataset))]
+        self.bufs = {}
+        for mod, cfg in dataset.modalities.items():
+            shape = (self.bs, len(cfg["channels"]), dataset.patch_sizes[mod], dataset.patch_sizes[mod])
+            self.bufs[mod] = [torch.empty(shape, dtype=torch.uint8).pin_memory() if torch.cuda.is_available()
+                              else torch.empty(shape, dtype=torch.uint8) for _ in range(2)]
+
+    @staticmethod
+    def supports(dataset) -> bool:
+        if not getattr(dataset, "device_normalize", False):
+            return False
+        for mod, reader in dataset.readers.items():
+            if dataset.norm_vectors(mod) is None or not hasattr(reader, "read_bounds"):
+                return False
+            if getattr(getattr(reader, "data", None), "dtype", None) != np.uint8:
+                return False
+        return True
+
+    def __len__(self) -> int:
+        return (len(self.ds) + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        n_total = len(self.ds)
+        for k, start in enumerate(range(0, n_total, self.bs)):
+            idx = list(range(start, min(start + self.bs, n_total)))
+            out = {}
+            for mod, cfg in self.ds.modalities.items():
+                buf = self.bufs[mod][k & 1]
+                arr = buf.numpy()
+                for j, i in enumerate(idx):
+                    self.ds.readers[mod].read_bounds(cfg["channels"], self.boxes[i], self.ds.patch_sizes[mod], out=arr[j])
+                out[mod] = buf[: len(idx)]
+            out["index"] = torch.tensor(idx, dtype=torch.long).unsqueeze(1)
+            yield out

@@ -29,7 +29,7 @@ from torch.utils.data import DataLoader
 
 from flairhip import ops
 from flair_zonal_detection.config import config_recap_1, config_recap_2, load_config, validate_config
-from flair_zonal_detection.dataset import MultiModalSlicedDataset
+from flair_zonal_detection.dataset import MultiModalSlicedDataset, TileBatcher
 from flair_zonal_detection.model_utils import build_inference_model, compute_patch_sizes
 from flair_zonal_detection.postprocess import convert  # noqa: F401  (re-exported like the reference)
 from flair_zonal_detection.raster import ArrayRaster, make_window, open_raster
@@ -187,26 +187,43 @@ def inference_and_write(model: torch.nn.Module, dataloader: DataLoader, tiles_gd
             if nv is not None:
                 norms[mod + "_NORM"] = torch.tensor(np.stack(nv), dtype=torch.float32, device=device)
 
+    # tile columns as plain arrays: a pandas row lookup costs ~0.5 ms, twice per tile
+    lefts, tops, ids = (np.asarray(tiles_gdf[c]) for c in ("left", "top", "id"))
+    graphed = None  # hipGraph of forward + conversion for full batches (the eval forward is ~120 launches)
+    use_graph = bool(config.get("hip_graph", True)) and str(device).startswith("cuda")
+
+    def forward_eager(inputs):
+        logits_tasks, _ = model(inputs)
+        preds = {}
+        for task_name, logits in logits_tasks.items():
+            preds[task_name] = ops.predict_u8(logits._ffa_nhwc, logits._ffa_classes, output_type,
+                                              crop=(margin, margin, keep, keep))
+        return preds
+
+    full = getattr(dataloader, "bs", None) or getattr(dataloader, "batch_size", None)
     for batch in dataloader:
         inputs = {k: v.to(device, non_blocking=True) for k, v in batch.items() if k != "index" and torch.is_tensor(v)}
         for k, v in norms.items():
             if inputs.get(k[:-5]) is not None and inputs[k[:-5]].dtype == torch.uint8:
                 inputs[k] = v
         indices = batch["index"].cpu().numpy().flatten()
-        rows = tiles_gdf.iloc[indices]
-        logits_tasks, _ = model(inputs)
-        for task_name, logits in logits_tasks.items():
-            nhwc = logits._ffa_nhwc
-            pred = ops.predict_u8(nhwc, logits._ffa_classes, output_type, crop=(margin, margin, keep, keep))
+        if use_graph and full and len(indices) == full:
+            if graphed is None:
+                from flairhip.graph import GraphedCall
+                graphed = GraphedCall(forward_eager, inputs)
+            preds = graphed(inputs)
+        else:
+            preds = forward_eager(inputs)
+        for task_name, pred in preds.items():
             if needs_rescale:
                 pred = _nearest_zoom(pred, scale)
             pred = pred.cpu().numpy()  # uint8: [B,h,w] or [B,K,h,w]
             for i in range(len(indices)):
-                row = rows.iloc[i]
+                ti = int(indices[i])
                 p = pred[i]
-                win = ops.write_window(row["left"], row["top"], img_bounds, out_res, p.shape[-2], p.shape[-1])
+                win = ops.write_window(lefts[ti], tops[ti], img_bounds, out_res, p.shape[-2], p.shape[-1])
                 if win.skip:
-                    logger.info("skipping tile %s: window out of bounds", row["id"])
+                    logger.info("skipping tile %s: window out of bounds", ids[ti])
                     continue
                 p = p[..., :win.height, :win.width]
                 window = make_window(win.col_off, win.row_off, win.width, win.height)
@@ -230,8 +247,11 @@ def run_inference(config_path, ref_raster=None, geozone=None) -> Dict[str, objec
     patch_sizes = compute_patch_sizes(config)
     model = build_inference_model(config, patch_sizes).to(config["device"])
     dataset = prep_dataset(config, tiles, patch_sizes)
-    loader = DataLoader(dataset, batch_size=config.get("batch_size", 8), num_workers=config.get("num_worker", 0),
-                        pin_memory=True)
+    if TileBatcher.supports(dataset) and not config.get("num_worker", 0):
+        loader = TileBatcher(dataset, config.get("batch_size", 8))  # uint8 tiles straight into pinned batch buffers
+    else:
+        loader = DataLoader(dataset, batch_size=config.get("batch_size", 8), num_workers=config.get("num_worker", 0),
+                            pin_memory=True)
     outputs, _ = init_outputs(config, ref_img)
     inference_and_write(model, loader, tiles, config, outputs, ref_img)
     logger.info("zonal inference of %d tiles took %.1f s", len(tiles), time.time() - t0)

@@ -70,9 +70,11 @@ class ArrayRaster:
         return {"driver": "MEM", "height": self.height, "width": self.width, "count": self.count,
                 "dtype": str(self.data.dtype), "crs": self.crs}
 
-    def read_bounds(self, indexes, bounds, out_size: int) -> np.ndarray:
+    def read_bounds(self, indexes, bounds, out_size: int, out: np.ndarray = None) -> np.ndarray:
         """Boundless read of the geographic box `bounds` = (left, bottom, right, top), zero fill outside the
-        raster, resampled to out_size x out_size when the box is not already that many pixels (bilinear)."""
+        raster, resampled to out_size x out_size when the box is not already that many pixels (bilinear).
+        ``out`` ([len(indexes), out_size, out_size], the raster's dtype) receives the tile in place when given
+        (the zonal loop passes a slot of its pinned batch buffer)."""
         l, b, r, t = bounds
         c0 = (l - self.left) / self._res
         r0 = (self.top - t) / self._res
@@ -81,11 +83,16 @@ class ArrayRaster:
         bands = [i - 1 for i in indexes]
         ci, ri, wi, hi = int(round(c0)), int(round(r0)), int(round(w)), int(round(h))
         if abs(c0 - ci) < 1e-6 and abs(r0 - ri) < 1e-6 and wi == out_size and hi == out_size:
-            out = np.zeros((len(bands), out_size, out_size), dtype=self.data.dtype)
             ys, ye = max(ri, 0), min(ri + hi, self.height)
             xs, xe = max(ci, 0), min(ci + wi, self.width)
+            inside = ys == ri and xs == ci and ye == ri + hi and xe == ci + wi
+            if out is None:
+                out = np.empty((len(bands), out_size, out_size), dtype=self.data.dtype)
+            if not inside:
+                out[...] = 0
             if ye > ys and xe > xs:
-                out[:, ys - ri:ye - ri, xs - ci:xe - ci] = self.data[bands, ys:ye, xs:xe]
+                for k, bnd in enumerate(bands):  # plain slices: no fancy-index temporary
+                    out[k, ys - ri:ye - ri, xs - ci:xe - ci] = self.data[bnd, ys:ye, xs:xe]
             return out
         # generic path: bilinear sampling at output pixel centres
         ys = r0 + (np.arange(out_size) + 0.5) * (h / out_size) - 0.5
@@ -99,9 +106,13 @@ class ArrayRaster:
             v = src[:, np.clip(yy, 0, self.height - 1)][:, :, np.clip(xx, 0, self.width - 1)]
             return v * ok[None]
 
-        out = (at(y0, x0) * (1 - fy) * (1 - fx) + at(y0, x0 + 1) * (1 - fy) * fx +
-               at(y0 + 1, x0) * fy * (1 - fx) + at(y0 + 1, x0 + 1) * fy * fx)
-        return out.astype(self.data.dtype) if np.issubdtype(self.data.dtype, np.floating) else out
+        out_ = (at(y0, x0) * (1 - fy) * (1 - fx) + at(y0, x0 + 1) * (1 - fy) * fx +
+                at(y0 + 1, x0) * fy * (1 - fx) + at(y0 + 1, x0 + 1) * fy * fx)
+        res_ = out_.astype(self.data.dtype) if np.issubdtype(self.data.dtype, np.floating) else out_
+        if out is not None:
+            out[...] = res_
+            return out
+        return res_
 
     def write(self, arr: np.ndarray, band: int, window=None) -> None:
         if window is None:

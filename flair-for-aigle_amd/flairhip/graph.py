@@ -84,3 +84,31 @@ class GraphedTrainStep:
         if self.after_step is not None:
             self.after_step()
         return self.loss
+
+
+class GraphedCall:
+    """fn(inputs: dict of tensors) -> dict of tensors, captured once into a HIP graph and replayed with new input
+    values copied into the static buffers.  For inference loops with a fixed batch shape (the zonal tile loop: eval
+    forward + margin-crop/argmax is ~120 kernel launches for 1.4 ms of GPU work at batch 8).  The returned tensors
+    are static buffers, valid until the next call."""
+
+    def __init__(self, fn, example_inputs: Dict[str, torch.Tensor], warmup: int = 2):
+        self.static_in = {k: v.clone() for k, v in example_inputs.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                fn(self.static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.static_out = fn(self.static_in)
+
+    def __call__(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        for k, dst in self.static_in.items():
+            src = inputs[k]
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.static_out

@@ -289,3 +289,36 @@ def test_argument_errors_are_reported_not_thrown(lib):
     assert lib.ffa_slice_grid(0.0, 0.0, 10.0, 10.0, 0.0, 0.0, 64, 32, 0.2, None, 0) == -1
     with pytest.raises(L.FlairHipError):
         L.check(rc, "conv2d")
+
+
+def test_tile_batcher_equals_dataset_plus_default_collate():
+    """the zonal loop's pinned-buffer batcher hands over exactly the tiles the Dataset / DataLoader path produces
+    (raw uint8, device-normalise mode), including the ragged last batch and tiles hanging over the raster edge"""
+    import pandas as pd
+    from torch.utils.data import DataLoader
+    from flair_zonal_detection.dataset import MultiModalSlicedDataset, TileBatcher
+    from flair_zonal_detection.raster import ArrayRaster
+    g = np.random.default_rng(5)
+    ras = ArrayRaster(g.integers(0, 255, (4, 90, 120), dtype=np.uint8), 1000.0, 2000.0, 0.5)
+    P = 32
+    boxes = []
+    for r0 in (-8, 20, 70):          # first tile hangs over the top edge, last over the bottom
+        for c0 in (-5, 40, 100):
+            left, top = 1000.0 + c0 * 0.5, 2000.0 - r0 * 0.5
+            boxes.append((left, top - P * 0.5, left + P * 0.5, top))
+    df = pd.DataFrame({"geometry": boxes, "left": [b[0] for b in boxes], "top": [b[3] for b in boxes],
+                       "id": [str(i) for i in range(len(boxes))]})
+    mods = {MOD: {"input_img_path": ras, "channels": [1, 2, 4],
+                  "normalization": {"type": "custom", "means": [1.0, 2.0, 3.0], "stds": [4.0, 5.0, 6.0]}}}
+    ds = MultiModalSlicedDataset(df, mods, {MOD: P}, "05-15", {"labels": [], "labels_configs": {}}, device_normalize=True)
+    assert TileBatcher.supports(ds)
+    got = [{k: v.clone() for k, v in b.items()} for b in TileBatcher(ds, 4)]  # buffers are reused two batches later
+    want = list(DataLoader(ds, batch_size=4))
+    assert len(got) == len(want) == 3 and got[-1][MOD].shape[0] == 1
+    for a, b in zip(got, want):
+        assert a[MOD].dtype == torch.uint8 and torch.equal(a[MOD], b[MOD]) and torch.equal(a["index"], b["index"])
+    mean, std = ds.norm_vectors(MOD)
+    assert list(mean) == [1.0, 2.0, 3.0] and list(std) == [4.0, 5.0, 6.0]
+    plain = MultiModalSlicedDataset(df, mods, {MOD: P}, "05-15", {"labels": [], "labels_configs": {}})
+    ref = (want[0][MOD][1].double() - torch.tensor(mean).double()[:, None, None]) / torch.tensor(std).double()[:, None, None]
+    assert torch.allclose(plain[1][MOD].double(), ref, atol=1e-6)  # host normalisation path unchanged

@@ -88,7 +88,9 @@ def main():
     mdl = build_inference_model(cfg2, sizes).to(cfg2["device"])
     t.append(time.time())
     ds = zi.prep_dataset(cfg2, tiles, sizes)
-    loader = DataLoader(ds, batch_size=args.batch, num_workers=0, pin_memory=True)
+    from flair_zonal_detection.dataset import TileBatcher
+    loader = TileBatcher(ds, args.batch) if TileBatcher.supports(ds) else DataLoader(ds, batch_size=args.batch,
+                                                                                     pin_memory=True)
     outputs, _ = zi.init_outputs(cfg2, ras)
     t.append(time.time())
     zi.inference_and_write(mdl, loader, tiles, cfg2, outputs, ras)
