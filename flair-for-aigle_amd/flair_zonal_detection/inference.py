@@ -236,14 +236,45 @@ def inference_and_write(model: torch.nn.Module, dataloader: DataLoader, tiles_gd
         dst.close()
 
 
-def run_inference(config_path, ref_raster=None, geozone=None) -> Dict[str, object]:
+def shard_tiles(tiles, rank: int, world: int):
+    """Tiles of one rank of a sharded run: a CONTIGUOUS slice of the grid order (outer loop x, inner y).  No
+    collective is needed -- tiles are independent units -- and contiguity keeps the reference's "last writer wins"
+    for the clamped last row / column inside a shard; across shards merge_shard_outputs restores it by rank order."""
+    if not (0 <= rank < world):
+        raise ValueError(f"shard rank {rank} outside world size {world}")
+    n = len(tiles)
+    return tiles.iloc[rank * n // world:(rank + 1) * n // world].reset_index(drop=True)
+
+
+def merge_shard_outputs(outputs_by_rank):
+    """One set of output rasters from the per-rank rasters of a sharded in-memory run (ArrayRaster with
+    track_writes): pixels a later rank wrote replace those of earlier ranks, i.e. grid order = write order."""
+    merged = {}
+    for task, first in outputs_by_rank[0].items():
+        out = ArrayRaster(first.data.copy(), first.left, first.top, first._res, first.crs)
+        for part in outputs_by_rank[1:]:
+            r = part[task]
+            if r.written is None:
+                raise ValueError("merge_shard_outputs needs rasters that tracked their writes")
+            out.data[:, r.written] = r.data[:, r.written]
+        merged[task] = out
+    return merged
+
+
+def run_inference(config_path, ref_raster=None, geozone=None, shard: Optional[Tuple[int, int]] = None
+                  ) -> Dict[str, object]:
     """End-to-end zonal run with upstream FLAIR-HUB's one-argument semantics (the fork's own run_inference is
-    stale: inference.py:650-665 calls its helpers with the wrong arity).  Returns the output rasters."""
+    stale: inference.py:650-665 calls its helpers with the wrong arity).  Returns the output rasters.
+    ``shard=(rank, world)`` (or config['shard']) restricts the run to that rank's slice of the tile grid: one process
+    per GPU, no communication; in-memory outputs then track their writes for merge_shard_outputs."""
     t0 = time.time()
     config = prep_config(config_path)
     ref_path = config["modalities"][config["reference_modality"]]["input_img_path"]
     ref_img = ref_raster if ref_raster is not None else open_raster(ref_path)
     tiles = generate_patches_from_reference(config, ref_img, geozone)
+    shard = shard if shard is not None else config.get("shard")
+    if shard is not None:
+        tiles = shard_tiles(tiles, int(shard[0]), int(shard[1]))
     patch_sizes = compute_patch_sizes(config)
     model = build_inference_model(config, patch_sizes).to(config["device"])
     dataset = prep_dataset(config, tiles, patch_sizes)
@@ -253,6 +284,10 @@ def run_inference(config_path, ref_raster=None, geozone=None) -> Dict[str, objec
         loader = DataLoader(dataset, batch_size=config.get("batch_size", 8), num_workers=config.get("num_worker", 0),
                             pin_memory=True)
     outputs, _ = init_outputs(config, ref_img)
+    if shard is not None:
+        for o in outputs.values():
+            if isinstance(o, ArrayRaster):
+                o.track_writes()
     inference_and_write(model, loader, tiles, config, outputs, ref_img)
     logger.info("zonal inference of %d tiles took %.1f s", len(tiles), time.time() - t0)
     return outputs

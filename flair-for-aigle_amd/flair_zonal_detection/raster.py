@@ -36,6 +36,11 @@ class ArrayRaster:
         self.data = data
         self.left, self.top, self._res, self.crs = float(left), float(top), float(res), crs
         self.closed = False
+        self.written = None  # optional [H, W] bool mask of the pixels write() touched (sharded runs merge by it)
+
+    def track_writes(self) -> "ArrayRaster":
+        self.written = np.zeros((self.height, self.width), dtype=bool)
+        return self
 
     @classmethod
     def empty_like(cls, ref: "ArrayRaster", count: int, dtype=np.uint8) -> "ArrayRaster":
@@ -120,6 +125,8 @@ class ArrayRaster:
             return
         c, r, w, h = int(window.col_off), int(window.row_off), int(window.width), int(window.height)
         self.data[band - 1, r:r + h, c:c + w] = arr
+        if self.written is not None:
+            self.written[r:r + h, c:c + w] = True
 
     def close(self) -> None:
         self.closed = True
