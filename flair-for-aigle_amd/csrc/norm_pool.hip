@@ -649,8 +649,8 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, u
 }
 
 template <typename T>
-__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx, int B,
-                                   int H, int W, int C, int Ho, int Wo) {
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, const T* __restrict__ add,
+                                   T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo) {
   // gather form: input pixel (iy, ix) is tap (r, s) of output (oy, ox) when iy = 2*oy - 1 + r
   const int CG = C / 8;
   const long long total = (long long)B * H * W * CG;
@@ -665,6 +665,7 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __re
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (add) ffa_load8<T>(add + i * 8, acc);  // a second gradient of the pooled tensor's input (U-Net skip), summed here
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int ty = iy + 1 - r;
@@ -708,17 +709,17 @@ extern "C" int ffa_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* 
   return ffa_check_launch("maxpool_fwd");
 }
 
-extern "C" int ffa_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int B, int H, int W,
-                                    int C, hipStream_t stream) {
+extern "C" int ffa_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* idx, const void* add, void* dx, int B,
+                                    int H, int W, int C, hipStream_t stream) {
   FFA_REQUIRE(dy && dx && idx && C % 8 == 0, "maxpool_bwd: bad arguments");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long long items = (long long)B * H * W * (C / 8);
   if (dtype == FFA_BF16)
     hipLaunchKernelGGL(maxpool_bwd_kernel<ffa_bf16>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
-                       (const ffa_bf16*)dy, idx, (ffa_bf16*)dx, B, H, W, C, Ho, Wo);
+                       (const ffa_bf16*)dy, idx, (const ffa_bf16*)add, (ffa_bf16*)dx, B, H, W, C, Ho, Wo);
   else
     hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
-                       (const float*)dy, idx, (float*)dx, B, H, W, C, Ho, Wo);
+                       (const float*)dy, idx, (const float*)add, (float*)dx, B, H, W, C, Ho, Wo);
   return ffa_check_launch("maxpool_bwd");
 }
 

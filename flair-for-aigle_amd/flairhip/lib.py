@@ -67,7 +67,7 @@ SIGNATURES = {
     "ffa_bn_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p, _ll, _p]),
     "ffa_channel_sums": (_i, [_i, _p, _ll, _i, _p, _p, _p, _ll, _p]),
     "ffa_maxpool3x3s2_fwd": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "ffa_maxpool3x3s2_bwd": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "ffa_maxpool3x3s2_bwd": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "ffa_nchw_to_nhwc": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ffa_u8_nchw_to_nhwc": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "ffa_nhwc_to_nchw": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -267,9 +267,10 @@ class _BasicBlock(torch.autograd.Function):
     summed by a separate elementwise pass over the block's input (16 such passes per step in ResNet-34)."""
 
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, blk):
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, wd, gd, bd, blk, fork=False):
         c1, n1, c2, n2 = blk.conv1, blk.bn1, blk.conv2, blk.bn2
         down = blk.downsample is not None
+        ctx.fork = fork
         x1, sc1, sh1, m1, r1 = ops.conv2d_bn_stats(x, c1.packed(x.dtype), c1.padding, c1.out_pitch, g1, b1,
                                                    n1.running_mean, n1.running_var, n1.momentum, n1.eps)
         n1.note_batch()
@@ -289,12 +290,16 @@ class _BasicBlock(torch.autograd.Function):
         y = ops.bn_apply(x2, sc2, sh2, residual=idt, relu=True)
         ctx.blk = blk
         ctx.save_for_backward(x, x1, y1, x2, y, xd, g1, b1, m1, r1, g2, b2, m2, r2, gd, bd, md, rd, sc1, sh1)
-        return y
+        # fork: the block's input also feeds the U-Net decoder; handing the alias out of THIS node lets its backward
+        # take the decoder's gradient of x as the residual input of a dgrad conv instead of an elementwise sum
+        return (y, x.view_as(x)) if fork else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dx_skip=None):
         x, x1, y1, x2, y, xd, g1, b1, m1, r1, g2, b2, m2, r2, gd, bd, md, rd, sc1, sh1 = ctx.saved_tensors
         blk = ctx.blk
+        if dx_skip is not None:
+            dx_skip = _as_nhwc_grad(dx_skip)
         c1, c2 = blk.conv1, blk.conv2
         dy = _as_nhwc_grad(dy)
 
@@ -323,9 +328,11 @@ class _BasicBlock(torch.autograd.Function):
             cd = blk.downsample[0]
             dd, _, dgd, dbd = ops.bn_bwd(xd, dres, None, gd, bd, md, rd, False, False)
             dwd = wgrad(cd, x, dd) if ctx.needs_input_grad[7] else None
-            dres = dgrad(cd, dd, x) if ctx.needs_input_grad[0] else None
+            dres = dgrad(cd, dd, x, residual=dx_skip) if ctx.needs_input_grad[0] else None  # second residual slot
+        elif dx_skip is not None:
+            dres = dres + dx_skip  # identity block used as a fork: no free epilogue slot (not the U-Net's case)
         dx = dgrad(c1, d1, x, residual=dres) if ctx.needs_input_grad[0] else None
-        return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None
+        return dx, dw1, dg1, db1, dw2, dg2, db2, dwd, dgd, dbd, None, None
 
 
 class _ConvBias(torch.autograd.Function):
@@ -421,6 +428,26 @@ class _MaxPool(torch.autograd.Function):
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
         return ops.maxpool3x3s2_bwd(_as_nhwc_grad(dy), idx, ctx.in_hw)
+
+
+class _MaxPoolFork(torch.autograd.Function):
+    """(pooled, x) from x: the ResNet stem output feeds the max-pool AND the U-Net skip.  As one node the two
+    gradients of x are summed inside the max-pool backward kernel instead of by a separate pass over x."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y, idx = ops.maxpool3x3s2_fwd(x)
+        ctx.save_for_backward(idx)
+        ctx.in_hw = (x.shape[1], x.shape[2])
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        (idx,) = ctx.saved_tensors
+        add = None if dskip is None else _as_nhwc_grad(dskip)
+        if dy is None:
+            return add
+        return ops.maxpool3x3s2_bwd(_as_nhwc_grad(dy), idx, ctx.in_hw, add=add)
 
 
 class _UpConcat(torch.autograd.Function):
@@ -541,15 +568,16 @@ def decoder_block(lo, skip, blk):
                                blk.conv2[1].weight, blk.conv2[1].bias, blk)
 
 
-def basic_block(x, blk):
-    """Training-mode forward of a BasicBlock module (conv1, bn1, conv2, bn2, downsample) as one autograd node."""
+def basic_block(x, blk, fork: bool = False):
+    """Training-mode forward of a BasicBlock module (conv1, bn1, conv2, bn2, downsample) as one autograd node.
+    fork=True -> (y, alias of x): hand the alias to the other consumer of x (the U-Net skip)."""
     if blk.downsample is not None:
         cd, nd = blk.downsample[0], blk.downsample[1]
         extra = (cd.weight, nd.weight, nd.bias)
     else:
         extra = (None, None, None)
     return _BasicBlock.apply(x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight,
-                             blk.bn2.bias, *extra, blk)
+                             blk.bn2.bias, *extra, blk, fork)
 
 
 def conv_bias(x, conv: HipConv2d):
@@ -567,6 +595,11 @@ def fusion_conv1x1(xs, splits, conv: HipConv2d):
 
 def max_pool(x):
     return _MaxPool.apply(x)
+
+
+def max_pool_fork(x):
+    """-> (max_pool(x), x): use the returned alias of x for the second consumer (see _MaxPoolFork)"""
+    return _MaxPoolFork.apply(x)
 
 
 def up_concat(lo, skip):

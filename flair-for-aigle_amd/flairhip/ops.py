@@ -451,13 +451,17 @@ def maxpool3x3s2_fwd(x: torch.Tensor):
     return y, idx
 
 
-def maxpool3x3s2_bwd(dy: torch.Tensor, idx: torch.Tensor, in_hw: Tuple[int, int]) -> torch.Tensor:
+def maxpool3x3s2_bwd(dy: torch.Tensor, idx: torch.Tensor, in_hw: Tuple[int, int],
+                     add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx = route(dy, idx) (+ add: another gradient of the pooled tensor's input, summed in the same pass)"""
     lib = _l.load()
     B, _, _, C_ = dy.shape
     H, W = in_hw
     dx = torch.empty((B, H, W, C_), dtype=dy.dtype, device=dy.device)
-    _l.check(lib.ffa_maxpool3x3s2_bwd(_dt(dy), dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), B, H, W, C_, _stream()),
-             "maxpool_bwd")
+    if add is not None and (tuple(add.shape) != tuple(dx.shape) or add.dtype != dx.dtype or not add.is_contiguous()):
+        raise ValueError("maxpool3x3s2_bwd: add must be a contiguous tensor of the input's shape and dtype")
+    _l.check(lib.ffa_maxpool3x3s2_bwd(_dt(dy), dy.data_ptr(), idx.data_ptr(), _ptr(add), dx.data_ptr(), B, H, W, C_,
+                                      _stream()), "maxpool_bwd")
     return dx
 
 

@@ -9,6 +9,7 @@ Layer table, channel widths and init: SURVEY.md section 8a / Appendix C.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -16,6 +17,7 @@ import torch.nn as nn
 
 from . import nn as hnn
 
+FUSED_FORKS = os.environ.get("FFA_FUSED_FORKS", "1") != "0"  # A/B switch: let autograd sum the skip gradients
 ENCODER_WIDTHS = (64, 128, 256, 512)
 ENCODER_BLOCKS = (3, 4, 6, 3)
 DECODER_CHANNELS = (256, 128, 64, 32, 16)
@@ -65,6 +67,22 @@ class ResNet34Encoder(nn.Module):
     def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
         feats = [x]
         x = hnn.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        if self.training and torch.is_grad_enabled() and FUSED_FORKS:
+            # Every skip feature has two consumers (next stage + decoder).  The consumer on the encoder side hands
+            # out the alias the decoder reads, so that its backward receives the decoder's gradient and adds it in a
+            # kernel it runs anyway (max-pool backward / a dgrad epilogue) instead of autograd's elementwise sum.
+            x, skip = hnn.max_pool_fork(x)
+            feats.append(skip)
+            for li in range(1, 5):
+                blocks = getattr(self, f"layer{li}")
+                for bi, blk in enumerate(blocks):
+                    if bi == 0 and li > 1:
+                        x, skip = hnn.basic_block(x, blk, fork=True)
+                        feats[-1] = skip
+                    else:
+                        x = blk(x)
+                feats.append(x)
+            return feats
         feats.append(x)
         x = hnn.max_pool(x)
         for li in range(1, 5):

@@ -136,8 +136,9 @@ int ffa_channel_sums(int dtype, const void* x, long long npix, int C, float* sum
                      void* workspace, long long workspace_bytes, ffa_stream_t stream);
 int ffa_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* idx, int B, int H, int W, int C,
                          ffa_stream_t stream);
-int ffa_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* idx, void* dx, int B, int H, int W, int C,
-                         ffa_stream_t stream);
+/* add (optional, shape of dx): a second gradient of the same tensor, e.g. the U-Net skip branch of the stem output */
+int ffa_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* idx, const void* add, void* dx, int B, int H, int W,
+                         int C, ffa_stream_t stream);
 
 /* ---- layout hand-over at the model boundary (batch dict tensors are NCHW f32:
  *      flair_hub/data/dataloader.py:105-257, flair_zonal_detection/dataset.py:174-209) -------------- */
