@@ -100,6 +100,10 @@ def load() -> C.CDLL:
         raise FlairHipError(
             f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950); "
             "there is no CPU fallback for the HIP hot path")
+    # torch first: its bundled HIP runtime must be the one already in the process when libflairhip.so (linked against
+    # libamdhip64) is mapped -- loaded the other way round the library binds to a second, uninitialised runtime and
+    # every launch fails with "no ROCm-capable device is detected"
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header and library out of sync
