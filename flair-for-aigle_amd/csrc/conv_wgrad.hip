@@ -829,6 +829,11 @@ static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, in
       if (p->wk == 1) {  // 64 x 64 channel blocks: eight waves, two k-split groups, 256-pixel tiles, one slab
         p->wk = 2;
         p->th *= 2;
+      } else if (p->wk == 4) {
+        // thin layers (<= 32 channels on both sides, HBM-bound): 256-pixel tiles = twice the bytes in flight per
+        // block, -9 % (512-pixel tiles spill); FFA_WG_THIN_SMALL=1 restores the 128-pixel tiles for A/B runs
+        static const bool small_tiles = getenv("FFA_WG_THIN_SMALL") && getenv("FFA_WG_THIN_SMALL")[0] == '1';
+        if (!small_tiles) p->th *= 2;
       }
     }
   } else {  // only the shapes the network needs are instantiated for the strided / 1x1 / stem kernels
@@ -917,6 +922,11 @@ static int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int kh, int kw, 
       FFA_WG_S1(2, 2, 2, 8, 16)
       FFA_WG_S1(2, 1, 2, 4, 8)
       FFA_WG_S1(1, 2, 2, 4, 8)
+      if (p.wco == 1 && p.wci == 1 && p.wk == 4 && (p.th == 8 && wide || p.th == 16 && !wide)) {
+        if (wide) launch_wgrad_cfg<T, 3, 3, 1, 3, 1, 1, 4, 8, 32>(a, 1, stream);
+        else launch_wgrad_cfg<T, 3, 3, 1, 3, 1, 1, 4, 16, 16>(a, 1, stream);
+        return ffa_check_launch("conv_wgrad");
+      }
       FFA_WG_S1(1, 1, 4, 4, 8)
     }
 #undef FFA_WG_S1
