@@ -37,11 +37,14 @@ class HipTrainer:
 
     def __init__(self, accelerator: str = "gpu", devices: int = 1, strategy: str = "auto", num_nodes: int = 1,
                  max_epochs: int = 1, default_root_dir: Optional[str] = None, monitor: str = "val_miou",
-                 monitor_mode: str = "max", max_steps: Optional[int] = None, **unused):
+                 monitor_mode: str = "max", max_steps: Optional[int] = None, hip_graph: bool = False, **unused):
         if accelerator not in ("gpu", "cuda", "auto"):
             raise RuntimeError("HipTrainer drives the MI355X path only (accelerator='gpu'); the CPU restatement "
                                "lives in oracle/ and is test infrastructure")
         self.max_epochs, self.max_steps = max_epochs, max_steps
+        # single process only: forward + loss + backward + optimizer captured once and replayed per batch
+        # (flairhip.graph.GraphedTrainStep); batches of another shape and modality dropout fall back to eager steps
+        self.hip_graph = bool(hip_graph)
         self.default_root_dir = default_root_dir
         self.monitor, self.monitor_mode = monitor, monitor_mode
         self.world_size = dist.get_world_size() if dist.is_initialized() else 1
@@ -78,15 +81,32 @@ class HipTrainer:
 
         best = None
         done = False
+        use_graph = (self.hip_graph and self.world_size == 1 and not getattr(model, "mod_dropout", False) and
+                     isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)))
+        graphed, graph_sig, loss = None, None, None
         for epoch in range(self.max_epochs):
             model.train()
             for i, batch in enumerate(train_dataloaders):
                 batch = _to_device(batch, self.device)
-                loss = model.training_step(batch, i)
-                optimizer.zero_grad(set_to_none=True)
-                loss.backward()
-                sync.finish()
-                optimizer.step()
+                if use_graph and graphed is None and model.global_step >= 2:
+                    # two ordinary steps first: they size every workspace, fill the weight-pack plan and create the
+                    # optimizer state, so the capture itself needs no warm-up steps that would move the weights
+                    from flairhip.graph import GraphedTrainStep
+                    # nothing may keep the previous step's autograd graph alive: its AccumulateGrad nodes are bound
+                    # to the stream they were created on, and running them from the capture stream aborts the capture
+                    loss = None
+                    graphed = GraphedTrainStep(model, optimizer, {k: v for k, v in batch.items() if torch.is_tensor(v)},
+                                               warmup_steps=0)
+                    graph_sig = {k: (tuple(v.shape), v.dtype) for k, v in batch.items() if torch.is_tensor(v)}
+                if graphed is not None and graph_sig == {k: (tuple(v.shape), v.dtype) for k, v in batch.items()
+                                                         if torch.is_tensor(v)}:
+                    loss = graphed({k: v for k, v in batch.items() if torch.is_tensor(v)})
+                else:
+                    loss = model.training_step(batch, i)
+                    optimizer.zero_grad(set_to_none=True)
+                    loss.backward()
+                    sync.finish()
+                    optimizer.step()
                 if scheduler is not None and interval == "step":
                     scheduler.step()
                 model.global_step += 1
@@ -160,7 +180,8 @@ def train(config: Dict[str, Any], data_module, seg_module, out_dir: str) -> HipT
                          strategy=hw.get("strategy", "auto"), num_nodes=hw.get("num_nodes", 1),
                          max_epochs=config["hyperparams"]["num_epochs"], default_root_dir=out_dir,
                          monitor=config.get("saving", {}).get("ckpt_monitor", "val_miou"),
-                         monitor_mode=config.get("saving", {}).get("ckpt_monitor_mode", "max"))
+                         monitor_mode=config.get("saving", {}).get("ckpt_monitor_mode", "max"),
+                         hip_graph=bool(hw.get("hip_graph", False)))
     trainer.fit(seg_module, datamodule=data_module)
     trainer.validate(seg_module, datamodule=data_module)
     return trainer

@@ -8,6 +8,11 @@ backward and the optimizer -- can be captured once into a HIP graph and replayed
 static buffers, one launch per step.  The learning-rate schedule stays on the host and writes the next value
 into the optimizer's device-resident ``lr`` tensor between replays.
 
+Capture hazard (found the hard way: segfault in hipStreamEndCapture): tensors that keep an EARLIER step's autograd
+graph alive (a stored loss) keep its AccumulateGrad nodes alive, and those run on the stream they were created on --
+from inside the capture that is an illegal cross-stream dependency.  Drop such references before constructing a
+GraphedTrainStep (HipTrainer does; the warm-up steps here never keep their loss).
+
 Single-process only: with world size > 1 the gradient all-reduce is issued from autograd hooks
 (flairhip.distributed.GradSync) and the step runs eagerly.
 """

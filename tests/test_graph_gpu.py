@@ -57,3 +57,25 @@ def test_graph_replay_matches_eager(cuda):
     assert torch.equal(we, wg), ((we - wg).norm() / we.norm()).item()
     assert int(cg.sum()) == int(ce.sum()) + 2 * 2 * 64 * 64  # + the two warm-up batches
     assert ng == ne + 2
+
+
+def test_trainer_graph_mode_follows_the_eager_trainer(cuda):
+    """HipTrainer(hip_graph=True): two eager steps, then the captured step; same loss trajectory as the eager trainer"""
+    from flair_hub.tasks.trainers import HipTrainer
+
+    def fit(hip_graph):
+        task, _, cfg = make_pair(precision="bf16", seed=3)
+        cfg["hyperparams"].update({"learning_rate": 1e-3, "total_steps": 6})
+        g = torch.Generator().manual_seed(2)
+        batches = [{MOD: torch.randn(2, 5, 64, 64, generator=g), TASK: torch.randint(0, 19, (2, 64, 64), generator=g)}
+                   for _ in range(6)]
+        losses = []
+        orig = task.on_train_batch_end
+        task.on_train_batch_end = lambda loss, batch, i: (losses.append(float(loss)), orig(loss, batch, i))[1]
+        HipTrainer(max_epochs=1, hip_graph=hip_graph).fit(task, train_dataloaders=batches)
+        return losses
+
+    eager, graph = fit(False), fit(True)
+    assert len(eager) == len(graph) == 6 and all(l == l for l in graph)
+    assert eager[:3] == graph[:3]  # the first two steps are the same code; the third loss depends only on them
+    assert all(abs(a - b) <= 5e-3 * abs(a) for a, b in zip(eager, graph))
