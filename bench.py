@@ -228,6 +228,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-symbol table to stderr")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of as one hipGraph replay")
+    ap.add_argument("--ddp-graph", action="store_true",
+                    help="N > 1: replay forward + backward as a hipGraph, then bucketed all-reduce + eager AdamW "
+                         "(default for N > 1: eager step, all-reduces from autograd hooks overlapped with backward)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -280,16 +283,26 @@ def main():
         return loss
 
     # single process: the whole step (forward, loss, metrics, backward, AdamW) is one hipGraph replay;
-    # multi process: eager, the RCCL all-reduces are issued from autograd hooks (flairhip.distributed)
-    use_graph = (world == 1) and not args.no_graph
+    # multi process: eager, the RCCL all-reduces are issued from autograd hooks and overlap backward
+    # (flairhip.distributed); --ddp-graph: forward + backward replayed as a graph, then the bucketed all-reduce of the
+    # gradients and an eager AdamW step (collectives stay outside the graph, no overlap)
+    use_graph = (not args.no_graph) and (world == 1 or args.ddp_graph)
     graphed = None
     if use_graph:
         from flairhip.graph import GraphedTrainStep
         try:
-            graphed = GraphedTrainStep(task, optimizer, batch, warmup_steps=3, after_step=scheduler.step)
+            if world == 1:
+                graphed = GraphedTrainStep(task, optimizer, batch, warmup_steps=3, after_step=scheduler.step)
+            else:
+                sync.remove()
+                sync = GradSync(task.model, hooks=False, broadcast_from_rank0=False)
+                graphed = GraphedTrainStep(task, optimizer, batch, warmup_steps=3, after_step=scheduler.step,
+                                           grad_reduce=sync.reduce_grads)
         except Exception as e:  # capture is an optimisation, never a requirement
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             use_graph = False
+            if world > 1:
+                sync = GradSync(task.model, broadcast_from_rank0=False)
     step = (lambda i: graphed(batch)) if use_graph else eager_step
 
     for i in range(args.warmup):

@@ -33,7 +33,7 @@ class _Bucket:
 
 class GradSync:
     def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20, process_group=None,
-                 broadcast_from_rank0: bool = True):
+                 broadcast_from_rank0: bool = True, hooks: bool = True):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params: List[torch.nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
@@ -41,7 +41,9 @@ class GradSync:
         self._fired: List[torch.nn.Parameter] = []
         self._buckets: Optional[List[_Bucket]] = None
         self._where = {}
-        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        # hooks=False: no autograd hooks; the caller hands the finished gradients to reduce_grads() (the hipGraph
+        # step: forward + backward are replayed as one graph, which cannot contain the collectives)
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if hooks else []
         if self.world > 1 and broadcast_from_rank0:
             with torch.no_grad():
                 for t in list(module.parameters()) + [b for b in module.buffers() if b.is_floating_point()]:
@@ -121,6 +123,27 @@ class GradSync:
             b.work = None
             b.flat.mul_(1.0 / self.world)
             b.pending = len(b.slots)
+
+    def reduce_grads(self, params, grads) -> None:
+        """Mean over ranks of ``grads`` (one tensor per parameter of ``params``, e.g. the static gradient tensors of a
+        replayed hipGraph), through the same flat buckets: copy in, one all-reduce per bucket (all in flight before
+        the first wait), scale, and point every ``p.grad`` at its bucket view for the optimizer."""
+        if self._buckets is None:
+            self._fired = list(params)
+            self._build_buckets()
+            self._fired = []
+        for p, g in zip(params, grads):
+            bi, off = self._where[p]
+            self._buckets[bi].flat[off: off + p.numel()].view_as(p).copy_(g)
+        if self.world > 1:
+            works = [dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                     for b in self._buckets]
+            for b, w in zip(self._buckets, works):
+                w.wait()
+                b.flat.mul_(1.0 / self.world)
+        for p in params:
+            bi, off = self._where[p]
+            p.grad = self._buckets[bi].flat[off: off + p.numel()].view_as(p)
 
     def remove(self) -> None:
         for h in self._handles:

@@ -13,8 +13,9 @@ graph alive (a stored loss) keep its AccumulateGrad nodes alive, and those run o
 from inside the capture that is an illegal cross-stream dependency.  Drop such references before constructing a
 GraphedTrainStep (HipTrainer does; the warm-up steps here never keep their loss).
 
-Single-process only: with world size > 1 the gradient all-reduce is issued from autograd hooks
-(flairhip.distributed.GradSync) and the step runs eagerly.
+With world size > 1 either the step runs eagerly with the gradient all-reduces issued from autograd hooks
+(flairhip.distributed.GradSync, overlapped with backward), or -- ``grad_reduce`` -- forward + backward are replayed
+as a graph and followed by the bucketed all-reduce and an eager optimizer step (collectives outside the graph).
 """
 from __future__ import annotations
 
@@ -38,14 +39,20 @@ def make_capturable(optimizer: torch.optim.Optimizer) -> None:
 
 
 class GraphedTrainStep:
-    """step(batch) -> loss tensor (static buffer, valid until the next call)."""
+    """step(batch) -> loss tensor (static buffer, valid until the next call).
+
+    ``grad_reduce(params, grads)`` (e.g. flairhip.distributed.GradSync(hooks=False).reduce_grads) switches to the
+    data-parallel form: only forward + loss + backward are captured, every replay is followed by the gradient
+    reduction and an eager ``optimizer.step()`` -- collectives stay outside the graph."""
 
     def __init__(self, task, optimizer: torch.optim.Optimizer, example_batch: Dict[str, torch.Tensor],
-                 warmup_steps: int = 3, after_step: Optional[Callable[[], None]] = None):
-        self.task, self.optimizer, self.after_step = task, optimizer, after_step
+                 warmup_steps: int = 3, after_step: Optional[Callable[[], None]] = None,
+                 grad_reduce: Optional[Callable] = None):
+        self.task, self.optimizer, self.after_step, self.grad_reduce = task, optimizer, after_step, grad_reduce
         self.static_batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
         self._bns = [m for m in task.modules() if isinstance(m, hnn.HipBatchNorm2d)]
-        make_capturable(optimizer)
+        if grad_reduce is None:
+            make_capturable(optimizer)
 
         # warm-up on a side stream: sizes every workspace, fills the weight-pack plan, creates optimizer state
         side = torch.cuda.Stream()
@@ -63,15 +70,22 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph):
             loss = task.training_step(self.static_batch, 0)
             loss.backward()
-            optimizer.step()
+            if grad_reduce is None:
+                optimizer.step()
         self.loss = loss
         for bn, n in zip(self._bns, pending):  # capture ran the Python but not the kernels
             bn._pending_batches = n
+        if grad_reduce is not None:  # the gradient tensors the replay rewrites in place
+            self.params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+            self.static_grads = [p.grad for p in self.params]
 
     def _eager_step(self, i: int):
         loss = self.task.training_step(self.static_batch, i)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        if self.grad_reduce is not None:
+            params = [p for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
+            self.grad_reduce(params, [p.grad for p in params])
         self.optimizer.step()
         if self.after_step is not None:
             self.after_step()
@@ -84,6 +98,9 @@ class GraphedTrainStep:
                 if dst.data_ptr() != v.data_ptr():
                     dst.copy_(v, non_blocking=True)
         self.graph.replay()
+        if self.grad_reduce is not None:
+            self.grad_reduce(self.params, self.static_grads)
+            self.optimizer.step()
         for bn in self._bns:  # host-side bookkeeping the replay skips
             bn.note_batch()
         if self.after_step is not None:

@@ -79,3 +79,43 @@ def test_trainer_graph_mode_follows_the_eager_trainer(cuda):
     assert len(eager) == len(graph) == 6 and all(l == l for l in graph)
     assert eager[:3] == graph[:3]  # the first two steps are the same code; the third loss depends only on them
     assert all(abs(a - b) <= 5e-3 * abs(a) for a, b in zip(eager, graph))
+
+
+def test_graph_plus_bucket_reduce_equals_the_eager_step(cuda):
+    """data-parallel form of the graph step (forward + backward replayed, gradients handed to GradSync.reduce_grads,
+    eager optimizer step): at world size 1 the reduction is the identity, so the trajectory is the eager one"""
+    from flairhip.distributed import GradSync
+    from flairhip.graph import GraphedTrainStep
+
+    def run(graph):
+        task, _, cfg = make_pair(precision="bf16", seed=13)
+        task.train()
+        g = torch.Generator().manual_seed(4)
+        batches = [{MOD: torch.randn(2, 5, 64, 64, generator=g).cuda(),
+                    TASK: torch.randint(0, 19, (2, 64, 64), generator=g).to(torch.uint8).cuda()} for _ in range(4)]
+        opt = torch.optim.AdamW(task.model.parameters(), lr=1e-3, weight_decay=0.01, fused=True)
+        losses = []
+        if graph:
+            state = {k: v.clone() for k, v in task.state_dict().items()}
+            sync = GradSync(task.model, hooks=False)
+            stepper = GraphedTrainStep(task, opt, batches[0], warmup_steps=2, grad_reduce=sync.reduce_grads)
+            task.load_state_dict(state)
+            for st in opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+            for b in batches:
+                losses.append(stepper(b).item())
+        else:
+            for b in batches:
+                loss = task.training_step(b, 0)
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+        w = task.model.state_dict()[f"encoders.{MOD}.seg_model.layer2.0.conv1.weight"].float().cpu()
+        return losses, w
+
+    le, we = run(False)
+    lg, wg = run(True)
+    assert le == lg and torch.equal(we, wg)
