@@ -32,10 +32,13 @@
 #define FFA_CONV_TRACE 0
 #endif
 #if FFA_CONV_TRACE
+#ifndef FFA_CONV_TRACE_FIRST
+#define FFA_CONV_TRACE_FIRST 0
+#endif
 __device__ long long ffa_conv_trace_buf[64 * 256];
 #define FFA_TRACE(slot_)                                                                    \
   if (trace_on) {                                                                           \
-    if (trace_n < 256) ffa_conv_trace_buf[blockIdx.x * 256 + trace_n] = (long long)(slot_) << 56 | (__builtin_readcyclecounter() & 0xFFFFFFFFFFFFFFLL); \
+    if (trace_n < 256) ffa_conv_trace_buf[(blockIdx.x - FFA_CONV_TRACE_FIRST) * 256 + trace_n] = (long long)(slot_) << 56 | (__builtin_readcyclecounter() & 0xFFFFFFFFFFFFFFLL); \
     ++trace_n;                                                                              \
   }
 #else
@@ -151,7 +154,8 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
 
   const int tid = threadIdx.x;
 #if FFA_CONV_TRACE
-  const bool trace_on = (threadIdx.x == 0 && blockIdx.x < 64);
+  // FFA_CONV_TRACE_FIRST: first traced block (a later dispatch round shows the steady state)
+  const bool trace_on = (threadIdx.x == 0 && (int)blockIdx.x >= FFA_CONV_TRACE_FIRST && (int)blockIdx.x < FFA_CONV_TRACE_FIRST + 64);
   int trace_n = 0;
 #endif
   FFA_TRACE(0)

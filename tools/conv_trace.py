@@ -28,8 +28,9 @@ def build_trace_lib() -> str:
     out_dir = os.path.join(B.CSRC, "build")
     obj = os.path.join(out_dir, "conv_igemm_trace.o")
     so = os.path.join(out_dir, "libflairhip_trace.so")
+    # FFA_CONV_TRACE_FIRST=<block id> traces 64 blocks of a later dispatch round (steady state) instead of the first
     flags = [f"--offload-arch={B.ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-DFFA_CONV_TRACE=1",
-             "-DFFA_WGRAD_TRACE=1"]
+             "-DFFA_WGRAD_TRACE=1", f"-DFFA_CONV_TRACE_FIRST={int(os.environ.get('FFA_CONV_TRACE_FIRST', '0'))}"]
     obj2 = os.path.join(out_dir, "conv_wgrad_trace.o")
     subprocess.run([B._hipcc()] + flags + ["-c", os.path.join(B.CSRC, "conv_igemm.hip"), "-o", obj], check=True)
     subprocess.run([B._hipcc()] + flags + ["-c", os.path.join(B.CSRC, "conv_wgrad.hip"), "-o", obj2], check=True)
