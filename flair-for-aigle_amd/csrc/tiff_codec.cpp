@@ -1,0 +1,259 @@
+// Block codecs of the GeoTIFF side of the zonal loop (host code, no GPU): TIFF-flavoured LZW and the horizontal
+// differencing predictor.
+//
+// The reference reaches these through rasterio / GDAL / libtiff: windowed reads of the input rasters
+// (flair_zonal_detection/dataset.py:89-117) and the LZW-compressed uint8 window writes of the prediction rasters
+// (flair_zonal_detection/inference.py:157-208 profile "compress": "lzw", :342-352 dst.write).  GDAL is absent from
+// the build image, so flair_zonal_detection/geotiff.py parses / emits the TIFF structure itself and calls in here
+// for the per-block byte work (a 25 000 x 25 000 px prediction raster is 9 600 blocks of 64 KiB).
+//
+// Bit-stream conventions are libtiff's ("new style" LZW, TIFF 6.0 section 13): codes are packed MSB first, start
+// at 9 bits, ClearCode = 256, EndOfInformation = 257, first free code 258, and the code width grows one code EARLY
+// (when the next free code reaches 2^bits - 1).  The encoder resets its table at 4094 entries, as libtiff does.
+#include <stdint.h>
+#include <string.h>
+
+#include "ffa_common_host.h"
+
+namespace {
+
+constexpr int kClear = 256;
+constexpr int kEoi = 257;
+constexpr int kFirst = 258;
+constexpr int kMaxBits = 12;
+constexpr int kTable = 1 << kMaxBits;
+
+struct BitReader {
+  const uint8_t* p;
+  const uint8_t* end;
+  uint64_t acc = 0;
+  int have = 0;
+  // next `bits`-wide code, or -1 when the stream is exhausted
+  int get(int bits) {
+    while (have < bits) {
+      if (p == end) return -1;
+      acc = (acc << 8) | *p++;
+      have += 8;
+    }
+    have -= bits;
+    return (int)((acc >> have) & ((1u << bits) - 1));
+  }
+};
+
+struct BitWriter {
+  uint8_t* p;
+  uint8_t* end;
+  uint64_t acc = 0;
+  int have = 0;
+  bool overflow = false;
+  void put(int code, int bits) {
+    acc = (acc << bits) | (uint32_t)code;
+    have += bits;
+    while (have >= 8) {
+      have -= 8;
+      if (p == end) {
+        overflow = true;
+        return;
+      }
+      *p++ = (uint8_t)(acc >> have);
+    }
+  }
+  void flush() {
+    if (have > 0) {
+      if (p == end) {
+        overflow = true;
+        return;
+      }
+      *p++ = (uint8_t)(acc << (8 - have));
+      have = 0;
+    }
+  }
+};
+
+}  // namespace
+
+// Worst-case size of ffa_tiff_lzw_encode's output for n input bytes (every byte its own 12-bit code, plus the
+// clear codes and the end marker).
+extern "C" long long ffa_tiff_lzw_bound(long long n) { return n + n / 2 + n / 1024 + 16; }
+
+// Decodes one LZW strip / tile.  Stops at EndOfInformation, at the end of the input, or when `cap` bytes have been
+// produced (writers pad blocks, readers know the decoded size).  Returns the number of bytes written, or
+// FFA_ERR_ARG for a corrupt stream.
+extern "C" long long ffa_tiff_lzw_decode(const uint8_t* src, long long n, uint8_t* dst, long long cap) {
+  if (!src || !dst || n < 0 || cap < 0) {
+    ffa_set_error("lzw_decode: bad arguments");
+    return FFA_ERR_ARG;
+  }
+  // table entry = (prefix code, last byte, length, first byte); strings are written back to front
+  static thread_local uint16_t prefix[kTable];
+  static thread_local uint8_t suffix[kTable];
+  static thread_local uint8_t first[kTable];
+  static thread_local uint16_t length[kTable];
+  for (int i = 0; i < 256; ++i) {
+    prefix[i] = 0;
+    suffix[i] = (uint8_t)i;
+    first[i] = (uint8_t)i;
+    length[i] = 1;
+  }
+  BitReader br{src, src + n};
+  if (n >= 2 && src[0] == 0 && (src[1] & 1)) {
+    ffa_set_error("lzw_decode: old-style (LSB-first) LZW streams are not supported");
+    return FFA_ERR_UNSUPPORTED;
+  }
+  int bits = 9, next = kFirst, old = -1;
+  long long out = 0;
+  while (out < cap) {
+    const int code = br.get(bits);
+    if (code < 0 || code == kEoi) break;
+    if (code == kClear) {
+      bits = 9;
+      next = kFirst;
+      old = -1;
+      continue;
+    }
+    if (old < 0) {  // first code after a clear must be a literal
+      if (code >= 256) {
+        ffa_set_error("lzw_decode: corrupt stream (code %d after clear)", code);
+        return FFA_ERR_ARG;
+      }
+      dst[out++] = (uint8_t)code;
+      old = code;
+      continue;
+    }
+    int len;
+    if (code < next) {
+      len = length[code];
+    } else if (code == next && next < kTable) {
+      len = length[old] + 1;
+    } else {
+      ffa_set_error("lzw_decode: corrupt stream (code %d, table holds %d)", code, next);
+      return FFA_ERR_ARG;
+    }
+    // new table entry: string(old) + first byte of the string just decoded
+    const uint8_t fb = (code < next) ? first[code] : first[old];
+    if (next < kTable) {
+      prefix[next] = (uint16_t)old;
+      suffix[next] = fb;
+      first[next] = first[old];
+      length[next] = (uint16_t)(length[old] + 1);
+      ++next;
+      if (next >= (1 << bits) - 1 && bits < kMaxBits) ++bits;
+    }
+    // write string(code) back to front, clipped to the output capacity
+    long long pos = out + len;
+    int c = code;
+    while (pos > out) {
+      --pos;
+      if (pos < cap) dst[pos] = suffix[c];
+      c = prefix[c];
+    }
+    out += len;
+    if (out > cap) out = cap;
+    old = code;
+  }
+  return out;
+}
+
+// Encodes n bytes as one LZW block.  Returns the encoded size, or FFA_ERR_WORKSPACE when `cap` is too small
+// (ffa_tiff_lzw_bound(n) always suffices).
+extern "C" long long ffa_tiff_lzw_encode(const uint8_t* src, long long n, uint8_t* dst, long long cap) {
+  if (!src || !dst || n < 0 || cap < 0) {
+    ffa_set_error("lzw_encode: bad arguments");
+    return FFA_ERR_ARG;
+  }
+  // open-addressing hash (prefix code, byte) -> code; a generation stamp makes the table reset free
+  constexpr int kHash = 1 << 14;
+  static thread_local uint32_t hkey[kHash];
+  static thread_local uint16_t hval[kHash];
+  static thread_local uint32_t hgen[kHash];
+  static thread_local uint32_t gen = 0;
+  auto reset = [&]() {
+    if (++gen == 0) {
+      memset(hgen, 0, sizeof(hgen));
+      gen = 1;
+    }
+  };
+  BitWriter bw{dst, dst + cap};
+  int bits = 9, next = kFirst;
+  reset();
+  bw.put(kClear, bits);
+  if (n > 0) {
+    int w = src[0];
+    for (long long i = 1; i < n; ++i) {
+      const int k = src[i];
+      const uint32_t key = ((uint32_t)w << 8) | (uint32_t)k;
+      uint32_t h = (key * 2654435761u) >> 18;  // 14 bits
+      int found = -1;
+      while (hgen[h] == gen) {
+        if (hkey[h] == key) {
+          found = hval[h];
+          break;
+        }
+        h = (h + 1) & (kHash - 1);
+      }
+      if (found >= 0) {
+        w = found;
+        continue;
+      }
+      bw.put(w, bits);
+      hgen[h] = gen;
+      hkey[h] = key;
+      hval[h] = (uint16_t)next;
+      ++next;
+      if (next == kTable - 2) {  // libtiff: table full at 4094 entries -> clear
+        bw.put(kClear, bits);
+        bits = 9;
+        next = kFirst;
+        reset();
+      } else if (next > (1 << bits) - 1) {
+        ++bits;
+      }
+      w = k;
+    }
+    bw.put(w, bits);
+    // the decoder adds one more entry after this code: keep the width of the end marker in step with it
+    ++next;
+    if (next == kTable - 2) {
+      bw.put(kClear, bits);
+      bits = 9;
+    } else if (next > (1 << bits) - 1 && bits < kMaxBits) {
+      ++bits;
+    }
+  }
+  bw.put(kEoi, bits);
+  bw.flush();
+  if (bw.overflow) {
+    ffa_set_error("lzw_encode: output buffer too small (%lld bytes for %lld input bytes)", cap, n);
+    return FFA_ERR_WORKSPACE;
+  }
+  return (long long)(bw.p - dst);
+}
+
+// TIFF Predictor = 2 (horizontal differencing) over `rows` rows of `row_samples` native-endian samples of
+// `sample_bytes` (1, 2 or 4) bytes each, `stride` samples between horizontally neighbouring values of one band
+// (= SamplesPerPixel for pixel-interleaved blocks, 1 for band-separate ones).  undo != 0 accumulates (read side),
+// undo == 0 differences (write side).  In place.
+extern "C" int ffa_tiff_hpredict(void* buf, long long rows, long long row_samples, int sample_bytes, int stride,
+                                 int undo) {
+  if (!buf || rows < 0 || row_samples < 0 || stride < 1 ||
+      !(sample_bytes == 1 || sample_bytes == 2 || sample_bytes == 4)) {
+    ffa_set_error("hpredict: bad arguments");
+    return FFA_ERR_ARG;
+  }
+#define FFA_HP(T_)                                                                 \
+  {                                                                                \
+    T_* p = static_cast<T_*>(buf);                                                 \
+    for (long long r = 0; r < rows; ++r, p += row_samples) {                       \
+      if (undo) {                                                                  \
+        for (long long i = stride; i < row_samples; ++i) p[i] = (T_)(p[i] + p[i - stride]); \
+      } else {                                                                     \
+        for (long long i = row_samples - 1; i >= stride; --i) p[i] = (T_)(p[i] - p[i - stride]); \
+      }                                                                            \
+    }                                                                              \
+  }
+  if (sample_bytes == 1) FFA_HP(uint8_t)
+  else if (sample_bytes == 2) FFA_HP(uint16_t)
+  else FFA_HP(uint32_t)
+#undef FFA_HP
+  return FFA_OK;
+}

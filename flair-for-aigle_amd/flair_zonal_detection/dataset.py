@@ -136,7 +136,7 @@ class TileBatcher:
         for mod, reader in dataset.readers.items():
             if dataset.norm_vectors(mod) is None or not hasattr(reader, "read_bounds"):
                 return False
-            if getattr(getattr(reader, "data", None), "dtype", None) != np.uint8:
+            if np.dtype(getattr(reader, "dtype", None) or object) != np.uint8:  # ArrayRaster / GeoTiffRaster of bytes
                 return False
         return True
 

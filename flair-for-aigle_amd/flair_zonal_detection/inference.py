@@ -131,6 +131,8 @@ def init_outputs(config: Dict, ref_img, i=None) -> Tuple[Dict[str, object], Dict
         count = k if output_type == "class_prob" else 1
         suffix = "argmax" if output_type == "argmax" else "class-prob"
         path = os.path.join(config["output_path"], f"{config['output_name']}_{task['name']}_{suffix}_i.tif")
+        if config.get("shard") is not None:  # one part file per rank; geotiff.merge_shard_files joins them
+            path = path[:-4] + ".r{}of{}.tif".format(*config["shard"])
         if needs_rescale:
             h = int(round((ib["top"] - ib["bottom"]) / out_res))
             w = int(round((ib["right"] - ib["left"]) / out_res))
@@ -140,14 +142,24 @@ def init_outputs(config: Dict, ref_img, i=None) -> Tuple[Dict[str, object], Dict
             outputs[task["name"]] = ArrayRaster(np.zeros((count, h, w), np.uint8), ib["left"], ib["top"], out_res,
                                                 ref_img.crs)
         else:
-            import rasterio  # type: ignore
-            from rasterio.transform import from_origin  # type: ignore
-            profile = ref_img.profile.copy()
-            profile.update({"count": count, "dtype": "uint8", "compress": "lzw"})
-            if needs_rescale:
-                profile.update({"driver": "GTiff", "height": h, "width": w,
-                                "transform": from_origin(ib["left"], ib["top"], out_res, out_res)})
-            outputs[task["name"]] = rasterio.open(path, "w", **profile)
+            try:
+                import rasterio  # type: ignore
+            except ImportError:
+                rasterio = None
+            if rasterio is None:  # no GDAL: the built-in GeoTIFF writer (tiled, LZW, written on close())
+                from flair_zonal_detection.geotiff import GeoTiffWriter
+                os.makedirs(config["output_path"], exist_ok=True)
+                outputs[task["name"]] = GeoTiffWriter.like(path, ref_img, count, np.uint8, width=w, height=h,
+                                                           left=ib["left"], top=ib["top"],
+                                                           res=out_res if needs_rescale else ref_img.res)
+            else:
+                from rasterio.transform import from_origin  # type: ignore
+                profile = ref_img.profile.copy()
+                profile.update({"count": count, "dtype": "uint8", "compress": "lzw"})
+                if needs_rescale:
+                    profile.update({"driver": "GTiff", "height": h, "width": w,
+                                    "transform": from_origin(ib["left"], ib["top"], out_res, out_res)})
+                outputs[task["name"]] = rasterio.open(path, "w", **profile)
         paths[task["name"]] = path
     return outputs, paths
 
@@ -274,6 +286,7 @@ def run_inference(config_path, ref_raster=None, geozone=None, shard: Optional[Tu
     tiles = generate_patches_from_reference(config, ref_img, geozone)
     shard = shard if shard is not None else config.get("shard")
     if shard is not None:
+        config["shard"] = (int(shard[0]), int(shard[1]))
         tiles = shard_tiles(tiles, int(shard[0]), int(shard[1]))
     patch_sizes = compute_patch_sizes(config)
     model = build_inference_model(config, patch_sizes).to(config["device"])

@@ -17,7 +17,7 @@ OUT = os.path.join(HERE, "libflairhip.so")
 OBJ = os.path.join(CSRC, "build")
 
 HIP_SOURCES = ["ffa_runtime.hip", "conv_igemm.hip", "conv_wgrad.hip", "norm_pool.hip", "resample_loss.hip"]
-CXX_SOURCES = ["tile_grid.cpp"]
+CXX_SOURCES = ["tile_grid.cpp", "tiff_codec.cpp"]
 HEADERS = ["ffa_common.h", "ffa_common_host.h", os.path.join("..", "..", "include", "flairhip.h")]
 ARCH = "gfx950"
 

@@ -84,6 +84,10 @@ SIGNATURES = {
     "ffa_confusion_matrix": (_i, [_p, _p, _ll, _i, _p, _p]),
     "ffa_slice_grid": (_ll, [_d, _d, _d, _d, _d, _d, _i, _i, _d, C.POINTER(Tile), _ll]),
     "ffa_write_window": (_i, [_d, _d, _d, _d, _d, _d, _d, _i, _i, C.POINTER(Window)]),
+    "ffa_tiff_lzw_bound": (_ll, [_ll]),
+    "ffa_tiff_lzw_decode": (_ll, [_p, _ll, _p, _ll]),
+    "ffa_tiff_lzw_encode": (_ll, [_p, _ll, _p, _ll]),
+    "ffa_tiff_hpredict": (_i, [_p, _ll, _ll, _i, _i, _i]),
     "ffa_probe_tr16": (_i, [_p, _p, _p]),
     "ffa_probe_mfma": (_i, [_p, _p, _p, _i, _p]),
 }

@@ -199,6 +199,20 @@ typedef struct {
 int ffa_write_window(double left, double top, double img_left, double img_bottom, double img_right, double img_top,
                      double out_res, int pred_h, int pred_w, ffa_window_t* out);
 
+/* ---- GeoTIFF block codecs (host side, no GPU): flair_zonal_detection/geotiff.py -------------------- */
+/* The reference reads its input rasters and writes its LZW-compressed uint8 prediction rasters through
+ * rasterio / GDAL / libtiff (flair_zonal_detection/dataset.py:89-117, inference.py:157-208 "compress": "lzw",
+ * :342-352 dst.write).  These are the per-block byte codecs of that format: libtiff-compatible LZW (MSB-first
+ * codes, early width change, table reset at 4094 entries) and the Predictor = 2 horizontal differencing. */
+long long ffa_tiff_lzw_bound(long long n);
+/* returns bytes written (stops at EndOfInformation, end of input or cap), < 0 on a corrupt stream */
+long long ffa_tiff_lzw_decode(const uint8_t* src, long long n, uint8_t* dst, long long cap);
+/* returns the encoded size, FFA_ERR_WORKSPACE when cap < what the stream needs (ffa_tiff_lzw_bound(n) suffices) */
+long long ffa_tiff_lzw_encode(const uint8_t* src, long long n, uint8_t* dst, long long cap);
+/* in place over rows x row_samples native-endian samples of sample_bytes (1, 2, 4); stride = samples between
+ * horizontal neighbours of one band; undo != 0 accumulates (read), 0 differences (write) */
+int ffa_tiff_hpredict(void* buf, long long rows, long long row_samples, int sample_bytes, int stride, int undo);
+
 /* ---- hardware layout probes (tests only) ---------------------------------------------------------- */
 int ffa_probe_tr16(const uint16_t* src, uint16_t* dst, ffa_stream_t stream);
 int ffa_probe_mfma(const float* A, const float* B, float* D, int use_f32, ffa_stream_t stream);
