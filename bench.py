@@ -73,7 +73,10 @@ class KernelTimer:
             flops = 2.0 * B * (Ho * Wo / (dil * dil)) * w.rows_real * w.ch_real * w.kh * w.kw
             tile = "8x32" if Wo >= 32 else "16x16"
             dt = "bf16" if x.dtype == torch.bfloat16 else "f32"
-            sym = f"conv_igemm_kernel<{dt},{w.kh}x{w.kw},s{w.stride},bco{w.bco},{tile}{_hk_tag(w, x.dtype)}>"
+            if ops.conv_is_persistent(x.dtype, B, Ho, Wo, w, dil):  # blocks walking several tiles: its own symbol
+                sym = f"conv3x3_persist_kernel<{dt},bco{w.bco},{tile}{_hk_tag(w, x.dtype)}>"
+            else:
+                sym = f"conv_igemm_kernel<{dt},{w.kh}x{w.kw},s{w.stride},bco{w.bco},{tile}{_hk_tag(w, x.dtype)}>"
             timer.records.append((sym, flops, s, e))
             return y
 
@@ -146,12 +149,19 @@ def pmc_traffic(symbol: str):
     if not os.path.exists(path):
         return None
     import re
+    kernels = json.load(open(path))["kernels"]
+    mp = re.match(r"conv3x3_persist_kernel<(bf16|f32),bco(\d+),(\d+)x(\d+),hk(\d)>", symbol)
+    if mp:  # template arguments <T, BCO, TH, TW, HK>
+        want = "void conv3x3_persist_kernel<{}, {}, {}, {}, {}>".format(
+            "ffa_bf16" if mp.group(1) == "bf16" else "float", *mp.group(2, 3, 4, 5))
+        hit = [v for name, v in kernels.items() if name.startswith(want)]
+        return round(hit[0]["hbm_bytes_per_launch"]) if hit else None
     m = re.match(r"(conv_igemm_kernel|conv_wgrad_kernel)<(bf16|f32),(\d)x\d,s(\d),(?:bco(\d+)|w(\d)x(\d)),?(\d+x\d+)?(?:,hk(\d))?", symbol)
     if not m:
         return None
     kind, dt, k, st = m.group(1), ("ffa_bf16" if m.group(2) == "bf16" else "float"), m.group(3), m.group(4)
     best = None
-    for name, v in json.load(open(path))["kernels"].items():
+    for name, v in kernels.items():
         if not name.startswith(f"void {kind}<{dt}, {k}, {k}, {st},"):
             continue
         if kind == "conv_igemm_kernel":

@@ -59,6 +59,7 @@ SIGNATURES = {
     "ffa_conv_wgrad_workspace_bytes": (_ll, [_i] * 9),
     "ffa_conv_wgrad": (_i, [_i, _p, _p, _p] + [_i] * 14 + [_p, _ll, _p]),
     "ffa_conv_wgrad_upcat": (_i, [_i, _p, _p, _p, _p] + [_i] * 8 + [_p, _ll, _p]),
+    "ffa_conv_is_persistent": (_i, [_i] * 11),
     "ffa_bn_workspace_bytes": (_ll, [_i]),
     "ffa_bn_stats": (_i, [_i, _p, _ll, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _ll, _p]),
     "ffa_bn_finalize": (_i, [_p, _ll, _ll, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _ll, _p]),

@@ -132,6 +132,13 @@ def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:
     return (h + 2 * pad - k) // stride + 1
 
 
+def conv_is_persistent(x_dtype, B: int, Ho: int, Wo: int, w: "PackedWeight", dil: int = 1) -> bool:
+    """True when conv2d runs this operand on conv3x3_persist_kernel (its own symbol in rocprofv3) rather than
+    conv_igemm_kernel; used by bench.py to group launches the way a profile does."""
+    return bool(_l.load().ffa_conv_is_persistent(_dtype_id(x_dtype), B, Ho, Wo,
+                                                 w.ci_pitch, w.rows, w.bco, w.kh, w.kw, w.stride, dil))
+
+
 def conv2d(x: torch.Tensor, w: PackedWeight, pad: int, out_channels: int, bias: Optional[torch.Tensor] = None,
            residual: Optional[torch.Tensor] = None, relu: bool = False, dil: int = 1,
            out_hw: Optional[Tuple[int, int]] = None, out: Optional[torch.Tensor] = None,

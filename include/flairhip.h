@@ -69,6 +69,11 @@ int ffa_conv2d(int dtype, const void* in, const void* w_packed, const float* bia
  * separate statistics pass of a training-mode BatchNorm that follows the convolution (torch.nn.functional.batch_norm
  * as called by smp's Conv2dReLU / torchvision's BasicBlock). */
 long long ffa_conv_stat_rows(int B, int Ho, int Wo);
+/* 1 when ffa_conv2d / ffa_conv2d_stats run this 3x3 stride-1 convolution on the persistent kernel
+ * (conv3x3_persist_kernel, blocks that walk several pixel tiles; opt-in with FFA_CONV_PERSIST=1), else 0.
+ * Profiling aid: the two kernels are separate symbols. */
+int ffa_conv_is_persistent(int dtype, int B, int Ho, int Wo, int Ci, int co_rows, int bco, int kh, int kw, int stride,
+                           int dil);
 int ffa_conv2d_stats(int dtype, const void* in, const void* w_packed, const float* bias, const void* residual,
                      void* out, float* stat_partials, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
                      int co_rows, int bco, int kh, int kw, int stride, int pad, int dil, int relu,

@@ -587,3 +587,47 @@ def test_u8_tiles_normalised_by_the_layout_kernel(cuda, dtype):
     assert got.shape == want.shape and float(got[..., 5:].float().abs().max()) == 0.0
     tol = 1e-6 if dtype == torch.float32 else 2 ** -8
     assert (got.float() - want.float()).abs().max().item() <= tol * 5.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("cin,cout,H,W,grid", [
+    (64, 64, 40, 72, 8),      # bf16: one group of four chunks per tile (every halo crosses tiles); 2 tiles / block
+    (128, 64, 33, 70, 16),    # two groups per tile, ragged tiles
+    (32, 32, 24, 40, 8),      # 32-row blocks; bf16: two chunks, HK = 2
+    (256, 128, 20, 20, 8),    # 16x16 tiles, two co blocks per pixel tile (the weight slab switches between tiles)
+    (64, 64, 16, 32, 64),     # fewer tiles than blocks: idle blocks leave at once
+])
+def test_persistent_conv_equals_the_plain_kernel(cuda, dtype, cin, cout, H, W, grid, monkeypatch):
+    """conv3x3_persist_kernel (FFA_CONV_PERSIST=1): blocks walk several tiles and prefetch across the tile boundary; output, bias / residual /
+    ReLU epilogue and the BatchNorm partial statistics are bit-identical to one block per tile"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(cin + cout + H)
+    B = 3
+    cip, cop = ops.pad_channels(cin), ops.pad_channels(cout)
+    x = to_nhwc(torch.randn(B, cin, H, W, generator=g), dtype, cuda, cip)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(cuda)
+    bias = torch.randn(cop, generator=g).to(cuda)
+    res = to_nhwc(torch.randn(B, cout, H, W, generator=g), dtype, cuda, cop)
+    pw = ops.pack_conv_weight(w, dtype, 1, cip)
+    rows = ops.conv_stat_rows(B, H, W)
+
+    def run():
+        st = torch.zeros(rows * 2 * cop, device=cuda)
+        y1 = ops.conv2d(x, pw, 1, cop, stats=st)
+        y2 = ops.conv2d(x, pw, 1, cop, bias=bias, residual=res, relu=True)
+        torch.cuda.synchronize()
+        return y1, st, y2
+
+    monkeypatch.delenv("FFA_CONV_PERSIST", raising=False)
+    ref = run()
+    monkeypatch.setenv("FFA_CONV_PERSIST", "1")
+    monkeypatch.setenv("FFA_CONV_PERSIST_MIN", "0")
+    monkeypatch.setenv("FFA_CONV_PERSIST_GRID", str(grid))
+    got = run()
+    for name, a_, b_ in zip(("conv", "stats", "conv+bias+res+relu"), got, ref):
+        if name == "stats" and dtype == torch.float32:
+            # same sums, but the two kernels are separate compilations: hipcc contracts r * r + s into an fma in one
+            # and not the other for the 32-row f32 variant (a few ulp on sums of 256 squares)
+            assert torch.allclose(a_, b_, rtol=2e-6, atol=1e-6), name
+        else:
+            assert torch.equal(a_, b_), name
