@@ -804,6 +804,64 @@ wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int
   }
 }
 
+// 3x3 variant: one block = one output channel x NQ quads of input channels, every thread keeps all nine taps of
+// its quad (36 sums).  The OIHW gradient [co][ci][tap] is then written as ONE contiguous run of NQ * 36 floats per
+// block; wgrad_reduce_kernel's thread-per-(tap, quad) mapping scatters 4-byte stores 36 bytes apart and touches
+// every 128-byte line of dw from nine different blocks (56 us for the 768 -> 256 decoder layer, 0.6 TB/s).
+// Summation order per element is the same as wgrad_reduce_kernel's (lane l adds slabs l, l + SL, ... ascending,
+// then the SL lane sums ascending), so the two kernels agree bit for bit.
+template <int SL>
+__global__ void __launch_bounds__(256)
+wgrad_reduce3x3_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int nsplit, int CoT, int CiT, int Co,
+                       int Ci, int accumulate) {
+  constexpr int NQ = 256 / SL;
+  constexpr int TAPS = 9;
+  constexpr int ROW = TAPS * 4 + 1;  // 37 floats per (lane, quad): odd -> conflict-free column walks
+  __shared__ float sh[SL * NQ * ROW];
+  const int ql = threadIdx.x % NQ, sl = threadIdx.x / NQ;
+  const int Cq = (Ci + 3) / 4;
+  const int qblocks = (Cq + NQ - 1) / NQ;
+  const int co = blockIdx.x / qblocks;
+  const int q0 = (blockIdx.x % qblocks) * NQ;
+  const int q = q0 + ql;
+  const size_t slab = (size_t)CoT * TAPS * CiT;
+  float acc[TAPS][4];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+  if (q < Cq) {
+    const float* src = slabs + (size_t)co * TAPS * CiT + q * 4;
+    for (int k = sl; k < nsplit; k += SL) {
+      ffa_f32x4 v[TAPS];
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) v[t] = *reinterpret_cast<const ffa_f32x4*>(src + (size_t)k * slab + t * CiT);
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] += v[t][e];
+    }
+  }
+  float* mine = sh + (sl * NQ + ql) * ROW;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mine[t * 4 + e] = acc[t][e];
+  __syncthreads();
+  // output run of this block: channels q0 * 4 .. of `co`, [ci][tap] contiguous in dw
+  const int ci_lo = q0 * 4;
+  const int nci = min(NQ * 4, Ci - ci_lo);
+  float* dst = dw + ((size_t)co * Ci + ci_lo) * TAPS;
+  for (int o = threadIdx.x; o < nci * TAPS; o += 256) {
+    const int cl = o / TAPS, tap = o % TAPS;
+    const float* col = sh + (cl >> 2) * ROW + tap * 4 + (cl & 3);
+    float t = 0.f;
+#pragma unroll 8
+    for (int l = 0; l < SL; ++l) t += col[l * NQ * ROW];
+    dst[o] = accumulate ? (dst[o] + t) : t;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 
 struct WgradPlan {
@@ -993,6 +1051,23 @@ static int wgrad_impl(int dtype, const void* x, const void* x2, int C1, const vo
                                : launch_wgrad<float>(a, p, kh, kw, stride, stream);
   if (rc != FFA_OK) return rc;
   const long long total = (long long)Co_real * kh * kw * ((Ci_real + 3) / 4);
+  const char* rv = getenv("FFA_WG_REDUCE_V1");  // A/B switch, read per call (tests flip it)
+  const bool reduce_v1 = rv && rv[0] == '1';
+  // contiguous OIHW runs per block, where that still fills the chip: one block per (output channel, quad group), so
+  // the thin layers (16-64 channels: 16-128 blocks walking 256 slabs each) stay on the thread-per-element kernel
+  // (measured +25 us each on the 16 / 32-channel decoder layers, -10...-15 us on the 256 / 512-channel ones)
+  const int cq = (Ci_real + 3) / 4;
+  const int v2_blocks = Co_real * ffa_cdiv(cq, p.nslab > 8 ? 8 : 64);
+  if (kh == 3 && kw == 3 && !reduce_v1 && v2_blocks >= 512) {
+    if (p.nslab > 8) {
+      hipLaunchKernelGGL(wgrad_reduce3x3_kernel<32>, dim3(v2_blocks), dim3(256), 0, stream,
+                         (const float*)workspace, dw_oihw, p.nslab, p.CoT, p.CiT, Co_real, Ci_real, accumulate);
+    } else {
+      hipLaunchKernelGGL(wgrad_reduce3x3_kernel<4>, dim3(v2_blocks), dim3(256), 0, stream,
+                         (const float*)workspace, dw_oihw, p.nslab, p.CoT, p.CiT, Co_real, Ci_real, accumulate);
+    }
+    return ffa_check_launch("wgrad_reduce3x3");
+  }
   if (p.nslab > 8) {
     long long g = (total + 7) / 8;
     if (g > 4096) g = 4096;

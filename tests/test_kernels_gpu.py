@@ -631,3 +631,27 @@ def test_persistent_conv_equals_the_plain_kernel(cuda, dtype, cin, cout, H, W, g
             assert torch.allclose(a_, b_, rtol=2e-6, atol=1e-6), name
         else:
             assert torch.equal(a_, b_), name
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("cin,cout,stride,H,W", [(64, 64, 1, 64, 96), (16, 19, 1, 40, 40), (768, 256, 1, 8, 8),
+                                               (64, 128, 2, 32, 32), (30, 34, 1, 24, 40)])
+def test_wgrad_reduce_with_contiguous_output_runs_is_bit_identical(cuda, dtype, cin, cout, stride, H, W, monkeypatch):
+    """wgrad_reduce3x3_kernel (one contiguous OIHW run per block) against the thread-per-(tap, quad) reduce it
+    replaces: same summation order, same bits; accumulate adds onto the existing gradient"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    B = 4
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    xd = to_nhwc(torch.randn(B, cin, H, W, generator=g), dtype, cuda)
+    dyd = to_nhwc(torch.randn(B, cout, Ho, Wo, generator=g), dtype, cuda, 32 if cout == 19 else (cout + 15) // 16 * 16)
+    base = torch.randn(cout, cin, 3, 3, generator=g).to(cuda)
+    monkeypatch.setenv("FFA_WG_REDUCE_V1", "1")
+    ref = ops.conv_wgrad(xd, dyd, cout, cin, 3, 3, stride, 1)
+    ref_acc = ops.conv_wgrad(xd, dyd, cout, cin, 3, 3, stride, 1, out=base.clone(), accumulate=True)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("FFA_WG_REDUCE_V1")
+    got = ops.conv_wgrad(xd, dyd, cout, cin, 3, 3, stride, 1)
+    got_acc = ops.conv_wgrad(xd, dyd, cout, cin, 3, 3, stride, 1, out=base.clone(), accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref) and torch.equal(got_acc, ref_acc)
