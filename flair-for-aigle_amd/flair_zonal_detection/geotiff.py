@@ -124,6 +124,8 @@ class GeoTiffRaster(RasterBase):
 
     def __init__(self, path: str, cache_bytes: int = 512 << 20):
         self.path = path
+        self._cache: "OrderedDict[int, np.ndarray]" = OrderedDict()
+        self._cache_bytes, self._cache_cap = 0, int(cache_bytes)
         self._f = open(path, "rb")
         try:
             self._mm = mmap.mmap(self._f.fileno(), 0, access=mmap.ACCESS_READ)
@@ -150,7 +152,18 @@ class GeoTiffRaster(RasterBase):
             self.close()
             raise GeoTiffError(f"{path}: bad TIFF magic {magic}")
         self._bo = bo
-        t, _ = _parse_ifd(mm, bo, big, ifd)
+        try:
+            t, _ = _parse_ifd(mm, bo, big, ifd)
+            self._init_from_tags(t)
+        except (struct.error, IndexError, KeyError) as e:  # truncated / inconsistent directory
+            self.close()
+            raise GeoTiffError(f"{path}: malformed TIFF directory ({type(e).__name__}: {e})") from e
+        except GeoTiffError:
+            self.close()
+            raise
+
+    def _init_from_tags(self, t: Dict[int, tuple]) -> None:
+        path, bo = self.path, self._bo
         self.tags = t
         self.width, self.height = int(t[_W][0]), int(t[_H][0])
         self.count = int(t.get(_SPP, (1,))[0])
@@ -207,8 +220,6 @@ class GeoTiffRaster(RasterBase):
         except ValueError:
             self.nodata = None
         self.closed = False
-        self._cache: "OrderedDict[int, np.ndarray]" = OrderedDict()
-        self._cache_bytes, self._cache_cap = 0, int(cache_bytes)
 
     # ---- rasterio-like attributes -------------------------------------------------------------------------
     @property
@@ -325,7 +336,8 @@ class GeoTiffRaster(RasterBase):
         self.closed = True
         self._cache = OrderedDict()
         try:
-            self._mm.close()
+            if getattr(self, "_mm", None) is not None:
+                self._mm.close()
         finally:
             self._f.close()
 

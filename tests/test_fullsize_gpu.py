@@ -1,0 +1,141 @@
+"""BASELINE.json configs[1] sizes on the GPU: 32 tiles of 512 x 512 x 5 per step, 19 classes.
+
+The CPU oracle needs minutes for a batch of that size, so parity at full size is carried by
+  (a) a direct comparison with the oracle on a two-tile sample AT THE FULL TILE SIZE, and
+  (b) size-independent properties that tie the whole batch to that sample: batch-partition invariance of the
+      eval-mode forward (bit-exact), batch statistics as a checksum of per-chunk checksums, the loss as the
+      weight-normalised sum of per-tile losses, gradients of the logits summing to zero per pixel, argmax
+      consistency, and run-to-run determinism of the full training step.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import MOD, TASK, make_pair
+
+pytestmark = pytest.mark.gpu
+
+B_FULL, TILE, CLASSES = 32, 512, 19
+WEIGHTS = torch.tensor([1.0] * 15 + [0.0] * 4)
+
+
+def _batch(n, seed=2025):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 5, TILE, TILE, generator=g)
+    t = torch.randint(0, CLASSES, (n, TILE, TILE), generator=g)
+    return x, t
+
+
+def test_full_size_tiles_match_the_oracle_and_the_batch_is_partition_invariant(cuda):
+    task, oracle, _ = make_pair(precision="fp32")
+    x, t = _batch(B_FULL)
+    oracle.eval()
+    with torch.no_grad():
+        ref = oracle(x[:2])  # two full-size tiles on the CPU: seconds
+    task.eval()
+    xd, td = x.to(cuda), t.to(cuda)
+    with torch.no_grad():
+        full = task.model({MOD: xd, TASK: td})[0][TASK]
+        parts = torch.cat([task.model({MOD: xd[i:i + 8], TASK: td[i:i + 8]})[0][TASK] for i in range(0, B_FULL, 8)])
+    assert full.shape == (B_FULL, CLASSES, TILE, TILE)
+    got = full[:2].float().cpu()
+    err = (got - ref).abs().max().item()
+    assert err <= 1e-4 * max(1.0, ref.abs().max().item()), f"logit error {err}"
+    assert (got.argmax(1) == ref.argmax(1)).float().mean().item() >= 0.9999
+    # every tile is computed independently of its batch neighbours: the 32-tile launch (other grid, other tile ->
+    # block mapping) gives the same bits as four 8-tile launches, so the sample above speaks for the whole batch
+    assert torch.equal(full, parts)
+
+
+def test_full_size_train_loss_matches_the_oracle_on_a_sample(cuda):
+    task, oracle, _ = make_pair(precision="fp32")
+    x, t = _batch(2, seed=7)
+    oracle.train()
+    ref = F.cross_entropy(oracle(x), t, weight=WEIGHTS)
+    task.train()
+    loss, preds, _ = task.step({MOD: x.to(cuda), TASK: t.to(cuda)}, training=True)
+    assert abs(loss.item() - ref.item()) <= 2e-5 * max(1.0, abs(ref.item()))
+    assert preds[TASK].shape == (2, TILE, TILE)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_batch_statistics_are_a_checksum_of_chunk_checksums(cuda, dtype):
+    """stem-sized layer at full size (32 x 256 x 256 x 64 outputs): the statistics that come out of the conv epilogue
+    equal the float64 combination of per-chunk sums of the stored output"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(11)
+    x = ops.nchw_to_nhwc(torch.randn(B_FULL, 64, 256, 256, generator=g).to(cuda), dtype)
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).to(cuda)
+    pw = ops.pack_conv_weight(w, dtype, 1, 64)
+    gamma, beta = torch.ones(64, device=cuda), torch.zeros(64, device=cuda)
+    rm, rv = torch.zeros(64, device=cuda), torch.ones(64, device=cuda)
+    y, scale, shift, mean, rstd = ops.conv2d_bn_stats(x, pw, 1, 64, gamma, beta, rm, rv, 0.1, 1e-5)
+    n = B_FULL * 256 * 256
+    s1 = torch.zeros(64, dtype=torch.float64, device=cuda)
+    s2 = torch.zeros(64, dtype=torch.float64, device=cuda)
+    for i in range(0, B_FULL, 4):  # chunk checksums, combined in float64
+        c = y[i:i + 4].double().reshape(-1, 64)
+        s1 += c.sum(0)
+        s2 += (c * c).sum(0)
+    m = s1 / n
+    var = s2 / n - m * m
+    assert torch.allclose(mean.double(), m, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rstd.double(), 1.0 / torch.sqrt(var + 1e-5), rtol=2e-5)
+    assert torch.allclose(rm.double(), 0.1 * m, rtol=1e-5, atol=1e-7)  # momentum update from zero
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_loss_and_logit_gradient_properties_at_full_size(cuda, dtype):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(13)
+    logits = torch.zeros(B_FULL, TILE, TILE, 32, dtype=dtype, device=cuda)
+    logits[..., :CLASSES] = (torch.randn(B_FULL, TILE, TILE, CLASSES, generator=g) * 3).to(cuda, dtype)
+    t = torch.randint(0, CLASSES, (B_FULL, TILE, TILE), generator=g).to(torch.uint8).to(cuda)
+    w = WEIGHTS.to(cuda)
+    loss, wsum, dl, pred = ops.softmax_ce(logits, t, w, CLASSES, want_grad=True, want_pred=True)
+    # the weighted mean over the batch is the weight-normalised sum of the per-tile losses
+    num = den = 0.0
+    for i in range(B_FULL):
+        li, wi, _, _ = ops.softmax_ce(logits[i:i + 1], t[i:i + 1], w, CLASSES)
+        num += li.double().item() * wi.double().item()
+        den += wi.double().item()
+    assert abs(wsum.item() - den) <= 1e-6 * den
+    assert abs(loss.item() - num / den) <= 2e-6 * abs(num / den)
+    assert wsum.item() == float((t < 15).sum().item())  # classes 15-18 carry weight 0
+    # predictions are the first maximum of the real classes; pad channels never win
+    assert torch.equal(pred, logits[..., :CLASSES].float().argmax(-1).to(torch.uint8))
+    # d loss / d logits: zero on zero-weight pixels and in the pad channels, sums to zero over the classes of a pixel
+    d = dl.float()
+    assert not d[..., CLASSES:].any()
+    assert not d[t >= 15].any()
+    tol = 1e-9 if dtype == torch.float32 else 3e-8  # of order 1/den per pixel, rounded per element in bf16
+    assert d.sum(-1).abs().max().item() <= tol
+    # and against autograd on one tile
+    z = logits[:1, ..., :CLASSES].float().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.cross_entropy(z, t[:1].long(), weight=w, reduction="sum")
+    ref.backward()
+    gref = z.grad.permute(0, 2, 3, 1) / wsum
+    err = (d[:1, ..., :CLASSES] - gref).abs().max().item()
+    assert err <= (1e-10 if dtype == torch.float32 else 2e-9 + 0.01 * gref.abs().max().item())
+
+
+def test_full_size_training_step_is_deterministic(cuda):
+    """the 32-tile bf16 training step twice from the same state: same loss bits, same bits in every gradient"""
+    task, _, _ = make_pair(precision="bf16")
+    x, t = _batch(B_FULL, seed=3)
+    batch = {MOD: x.to(cuda), TASK: t.to(cuda)}
+    task.train()
+    state = {k: v.clone() for k, v in task.model.state_dict().items()}
+    runs = []
+    for _ in range(2):
+        task.model.load_state_dict(state)
+        task.model.zero_grad(set_to_none=True)
+        loss, _, _ = task.step(batch, training=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.detach().clone(), {n: p.grad.clone() for n, p in task.model.named_parameters()
+                                             if p.grad is not None}))
+    assert torch.isfinite(runs[0][0]) and torch.equal(runs[0][0], runs[1][0])
+    assert runs[0][1].keys() == runs[1][1].keys() and len(runs[0][1]) > 100
+    for n, g0 in runs[0][1].items():
+        assert torch.equal(g0, runs[1][1][n]), n

@@ -292,3 +292,17 @@ def test_merge_shard_files_applies_parts_in_rank_order(tmp_path):
     out = merge_shard_files(paths, str(tmp_path / "merged.tif"), rows_per_pass=32)
     with GeoTiffRaster(out) as r:
         assert np.array_equal(r.read(), want)
+
+
+def test_truncated_directory_is_a_geotiff_error(tmp_path):
+    g = np.random.default_rng(12)
+    blob = _assemble("<", False, g.integers(0, 9, (1, 8, 8)).astype(np.uint16), 1, 8)
+    (ifd,) = struct.unpack_from("<I", blob, 4)
+    p = tmp_path / "cut.tif"
+    p.write_bytes(blob[:ifd + 20])  # directory cut short
+    with pytest.raises(GeoTiffError, match="malformed"):
+        GeoTiffRaster(str(p))
+    q = tmp_path / "nodims.tif"
+    q.write_bytes(b"II" + struct.pack("<HI", 42, 8) + struct.pack("<H", 0) + struct.pack("<I", 0))  # empty directory
+    with pytest.raises(GeoTiffError, match="malformed"):
+        GeoTiffRaster(str(q))
