@@ -84,72 +84,71 @@ extern "C" long long ffa_tiff_lzw_decode(const uint8_t* src, long long n, uint8_
     ffa_set_error("lzw_decode: bad arguments");
     return FFA_ERR_ARG;
   }
-  // table entry = (prefix code, last byte, length, first byte); strings are written back to front
-  static thread_local uint16_t prefix[kTable];
-  static thread_local uint8_t suffix[kTable];
-  static thread_local uint8_t first[kTable];
-  static thread_local uint16_t length[kTable];
-  for (int i = 0; i < 256; ++i) {
-    prefix[i] = 0;
-    suffix[i] = (uint8_t)i;
-    first[i] = (uint8_t)i;
-    length[i] = 1;
-  }
-  BitReader br{src, src + n};
   if (n >= 2 && src[0] == 0 && (src[1] & 1)) {
     ffa_set_error("lzw_decode: old-style (LSB-first) LZW streams are not supported");
     return FFA_ERR_UNSUPPORTED;
   }
-  int bits = 9, next = kFirst, old = -1;
-  long long out = 0;
+  // The table holds no strings, only where in the OUTPUT each one was first written: the entry created after
+  // emitting string(old) is string(old) + first byte of the next string, and those bytes sit contiguously in dst
+  // starting at the position string(old) was emitted at.  Decoding a code is one short copy within dst.
+  // (thread-local storage is resolved ONCE into plain pointers: in a -fPIC library every direct access to a
+  // thread_local array is a call to __tls_get_addr)
+  static thread_local uint32_t tl_where[kTable];
+  static thread_local uint16_t tl_length[kTable];
+  uint32_t* const where = tl_where;
+  uint16_t* const length = tl_length;
+  BitReader br{src, src + n};
+  int bits = 9, next = kFirst;
+  bool have_prev = false;
+  long long out = 0, prev_pos = 0;
+  int prev_len = 0;
   while (out < cap) {
     const int code = br.get(bits);
     if (code < 0 || code == kEoi) break;
     if (code == kClear) {
       bits = 9;
       next = kFirst;
-      old = -1;
+      have_prev = false;
       continue;
     }
-    if (old < 0) {  // first code after a clear must be a literal
-      if (code >= 256) {
-        ffa_set_error("lzw_decode: corrupt stream (code %d after clear)", code);
-        return FFA_ERR_ARG;
-      }
-      dst[out++] = (uint8_t)code;
-      old = code;
-      continue;
-    }
+    const long long pos = out;
     int len;
-    if (code < next) {
+    if (code < 256) {
+      dst[out++] = (uint8_t)code;
+      len = 1;
+    } else if (!have_prev) {  // first code after a clear must be a literal
+      ffa_set_error("lzw_decode: corrupt stream (code %d after clear)", code);
+      return FFA_ERR_ARG;
+    } else if (code < next) {
       len = length[code];
+      const uint8_t* from = dst + where[code];  // written earlier in full (where + len <= out): no overlap
+      const long long m = (out + len <= cap) ? len : cap - out;
+      if (m <= 16) {
+        for (long long i = 0; i < m; ++i) dst[out + i] = from[i];
+      } else {
+        memcpy(dst + out, from, (size_t)m);
+      }
+      out += m;
     } else if (code == next && next < kTable) {
-      len = length[old] + 1;
+      // string(old) + its own first byte: the source run ends on the byte being written -> forward byte copy
+      len = prev_len + 1;
+      const uint8_t* from = dst + prev_pos;
+      const long long m = (out + len <= cap) ? len : cap - out;
+      for (long long i = 0; i < m; ++i) dst[out + i] = from[i];
+      out += m;
     } else {
       ffa_set_error("lzw_decode: corrupt stream (code %d, table holds %d)", code, next);
       return FFA_ERR_ARG;
     }
-    // new table entry: string(old) + first byte of the string just decoded
-    const uint8_t fb = (code < next) ? first[code] : first[old];
-    if (next < kTable) {
-      prefix[next] = (uint16_t)old;
-      suffix[next] = fb;
-      first[next] = first[old];
-      length[next] = (uint16_t)(length[old] + 1);
+    if (have_prev && next < kTable) {
+      where[next] = (uint32_t)prev_pos;
+      length[next] = (uint16_t)(prev_len + 1);
       ++next;
       if (next >= (1 << bits) - 1 && bits < kMaxBits) ++bits;
     }
-    // write string(code) back to front, clipped to the output capacity
-    long long pos = out + len;
-    int c = code;
-    while (pos > out) {
-      --pos;
-      if (pos < cap) dst[pos] = suffix[c];
-      c = prefix[c];
-    }
-    out += len;
-    if (out > cap) out = cap;
-    old = code;
+    have_prev = true;
+    prev_pos = pos;
+    prev_len = len;
   }
   return out;
 }
@@ -163,13 +162,17 @@ extern "C" long long ffa_tiff_lzw_encode(const uint8_t* src, long long n, uint8_
   }
   // open-addressing hash (prefix code, byte) -> code; a generation stamp makes the table reset free
   constexpr int kHash = 1 << 14;
-  static thread_local uint32_t hkey[kHash];
-  static thread_local uint16_t hval[kHash];
-  static thread_local uint32_t hgen[kHash];
-  static thread_local uint32_t gen = 0;
+  static thread_local uint32_t tl_hkey[kHash];
+  static thread_local uint16_t tl_hval[kHash];
+  static thread_local uint32_t tl_hgen[kHash];
+  static thread_local uint32_t tl_gen = 0;
+  uint32_t* const hkey = tl_hkey;  // resolved once, see ffa_tiff_lzw_decode
+  uint16_t* const hval = tl_hval;
+  uint32_t* const hgen = tl_hgen;
+  uint32_t gen = tl_gen;
   auto reset = [&]() {
     if (++gen == 0) {
-      memset(hgen, 0, sizeof(hgen));
+      memset(hgen, 0, sizeof(tl_hgen));
       gen = 1;
     }
   };
@@ -220,6 +223,7 @@ extern "C" long long ffa_tiff_lzw_encode(const uint8_t* src, long long n, uint8_
       ++bits;
     }
   }
+  tl_gen = gen;
   bw.put(kEoi, bits);
   bw.flush();
   if (bw.overflow) {

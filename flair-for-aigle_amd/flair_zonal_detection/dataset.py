@@ -115,19 +115,23 @@ class TileBatcher:
     rasters read uint8 and accept ``read_bounds(..., out=)``; use ``TileBatcher.supports(dataset)``.
 
     Yields the same dict a DataLoader over the dataset would: {'<MOD>': uint8 [n,C,P,P], 'index': int64 [n,1]}.
-    Two buffers per modality alternate, so a batch stays valid until the batch after next is requested."""
+    Four buffers per modality rotate, so a batch stays valid until three more have been requested (the reader thread
+    runs one batch ahead of the consumer, which itself keeps one batch in flight on the device)."""
 
-    def __init__(self, dataset: MultiModalSlicedDataset, batch_size: int):
+    NBUF = 4  # a buffer is rewritten four batches later: the loop has synchronised on that batch's output by then
+
+    def __init__(self, dataset: MultiModalSlicedDataset, batch_size: int, prefetch: bool = True):
         if not self.supports(dataset):
             raise ValueError("TileBatcher needs device_normalize uint8 rasters with read_bounds(..., out=)")
         self.ds = self.dataset = dataset
         self.bs = self.batch_size = int(batch_size)
+        self.prefetch = bool(prefetch)  # read (and decode) the next batch on a worker thread while the device runs
         self.boxes = [dataset._tile_box(dataset.df.iloc[i]) for i in range(len(dataset))]
         self.bufs = {}
         for mod, cfg in dataset.modalities.items():
             shape = (self.bs, len(cfg["channels"]), dataset.patch_sizes[mod], dataset.patch_sizes[mod])
             self.bufs[mod] = [torch.empty(shape, dtype=torch.uint8).pin_memory() if torch.cuda.is_available()
-                              else torch.empty(shape, dtype=torch.uint8) for _ in range(2)]
+                              else torch.empty(shape, dtype=torch.uint8) for _ in range(self.NBUF)]
 
     @staticmethod
     def supports(dataset) -> bool:
@@ -143,16 +147,56 @@ class TileBatcher:
     def __len__(self) -> int:
         return (len(self.ds) + self.bs - 1) // self.bs
 
+    def _fill(self, k: int, start: int):
+        idx = list(range(start, min(start + self.bs, len(self.ds))))
+        out = {}
+        for mod, cfg in self.ds.modalities.items():
+            buf = self.bufs[mod][k % self.NBUF]
+            arr = buf.numpy()
+            for j, i in enumerate(idx):
+                self.ds.readers[mod].read_bounds(cfg["channels"], self.boxes[i], self.ds.patch_sizes[mod], out=arr[j])
+            out[mod] = buf[: len(idx)]
+        out["index"] = torch.tensor(idx, dtype=torch.long).unsqueeze(1)
+        return out
+
     def __iter__(self):
-        n_total = len(self.ds)
-        for k, start in enumerate(range(0, n_total, self.bs)):
-            idx = list(range(start, min(start + self.bs, n_total)))
-            out = {}
-            for mod, cfg in self.ds.modalities.items():
-                buf = self.bufs[mod][k & 1]
-                arr = buf.numpy()
-                for j, i in enumerate(idx):
-                    self.ds.readers[mod].read_bounds(cfg["channels"], self.boxes[i], self.ds.patch_sizes[mod], out=arr[j])
-                out[mod] = buf[: len(idx)]
-            out["index"] = torch.tensor(idx, dtype=torch.long).unsqueeze(1)
-            yield out
+        starts = list(enumerate(range(0, len(self.ds), self.bs)))
+        if not self.prefetch or len(starts) < 2:
+            for k, start in starts:
+                yield self._fill(k, start)
+            return
+        # one batch ahead on a worker thread: raster reads (block decode, big numpy copies) release the GIL
+        import queue
+        import threading
+        q: "queue.Queue" = queue.Queue(maxsize=1)
+        stop = threading.Event()
+
+        def produce():
+            try:
+                for k, start in starts:
+                    if stop.is_set():
+                        return
+                    item = self._fill(k, start)
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+                q.put(None)
+            except BaseException as e:  # surfaces in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=produce, name="tile-reader", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+            th.join(timeout=5.0)

@@ -54,13 +54,14 @@ def _codec():
 
 
 _POOL: Optional[ThreadPoolExecutor] = None
+_POOL_WORKERS = max(1, min(16, os.cpu_count() or 1))
 
 
 def _pool() -> ThreadPoolExecutor:
     """shared decode / encode workers (ctypes calls and zlib release the GIL)"""
     global _POOL
     if _POOL is None:
-        _POOL = ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1)), thread_name_prefix="geotiff")
+        _POOL = ThreadPoolExecutor(_POOL_WORKERS, thread_name_prefix="geotiff")
     return _POOL
 
 
@@ -301,8 +302,15 @@ class GeoTiffRaster(RasterBase):
                 missing.append(i)
         if missing:
             compressed = self._comp != 1
-            loaded = list(_pool().map(self._load_block, missing)) if compressed and len(missing) > 1 \
-                else [self._load_block(i) for i in missing]
+            if compressed and len(missing) > 3:
+                # a handful of blocks per task: a pool task costs ~30 us of Python, a 64 KiB block ~300 us to decode
+                nw = min(_POOL_WORKERS, len(missing) // 2)
+                parts = [missing[i::nw] for i in range(nw)]
+                done = _pool().map(lambda ids_: [self._load_block(i) for i in ids_], parts)
+                by_id = {i: a for ids_, arrs in zip(parts, done) for i, a in zip(ids_, arrs)}
+                loaded = [by_id[i] for i in missing]
+            else:
+                loaded = [self._load_block(i) for i in missing]
             for i, a in zip(missing, loaded):
                 got[i] = a
                 self._cache[i] = a

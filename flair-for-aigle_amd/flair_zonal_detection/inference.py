@@ -212,24 +212,11 @@ def inference_and_write(model: torch.nn.Module, dataloader: DataLoader, tiles_gd
                                               crop=(margin, margin, keep, keep))
         return preds
 
-    full = getattr(dataloader, "bs", None) or getattr(dataloader, "batch_size", None)
-    for batch in dataloader:
-        inputs = {k: v.to(device, non_blocking=True) for k, v in batch.items() if k != "index" and torch.is_tensor(v)}
-        for k, v in norms.items():
-            if inputs.get(k[:-5]) is not None and inputs[k[:-5]].dtype == torch.uint8:
-                inputs[k] = v
-        indices = batch["index"].cpu().numpy().flatten()
-        if use_graph and full and len(indices) == full:
-            if graphed is None:
-                from flairhip.graph import GraphedCall
-                graphed = GraphedCall(forward_eager, inputs)
-            preds = graphed(inputs)
-        else:
-            preds = forward_eager(inputs)
-        for task_name, pred in preds.items():
-            if needs_rescale:
-                pred = _nearest_zoom(pred, scale)
-            pred = pred.cpu().numpy()  # uint8: [B,h,w] or [B,K,h,w]
+    def write_batch(indices, host_preds):
+        """host side of one batch: window placement + raster writes (reference inference.py:297-352)"""
+        for task_name, (buf, done) in host_preds.items():
+            done.synchronize()
+            pred = buf[:len(indices)].numpy()  # uint8: [B,h,w] or [B,K,h,w]
             for i in range(len(indices)):
                 ti = int(indices[i])
                 p = pred[i]
@@ -244,6 +231,45 @@ def inference_and_write(model: torch.nn.Module, dataloader: DataLoader, tiles_gd
                 else:
                     for c in range(p.shape[0]):
                         output_files[task_name].write(p[c], c + 1, window=window)
+
+    # Two-stage software pipeline: the device works on batch k (H2D, forward, conversion, D2H into a pinned buffer,
+    # all stream-ordered and asynchronous) while the host writes the windows of batch k-1 and reads the tiles of
+    # batch k+1.  Pinned D2H buffers alternate; the loader's input buffers do too (TileBatcher).
+    full = getattr(dataloader, "bs", None) or getattr(dataloader, "batch_size", None)
+    host_bufs: Dict[str, list] = {}
+    pending = None
+    for k, batch in enumerate(dataloader):
+        inputs = {k_: v.to(device, non_blocking=True) for k_, v in batch.items()
+                  if k_ != "index" and torch.is_tensor(v)}
+        for k_, v in norms.items():
+            if inputs.get(k_[:-5]) is not None and inputs[k_[:-5]].dtype == torch.uint8:
+                inputs[k_] = v
+        indices = batch["index"].cpu().numpy().flatten()
+        if use_graph and full and len(indices) == full:
+            if graphed is None:
+                from flairhip.graph import GraphedCall
+                graphed = GraphedCall(forward_eager, inputs)
+            preds = graphed(inputs)
+        else:
+            preds = forward_eager(inputs)
+        host_preds = {}
+        for task_name, pred in preds.items():
+            if needs_rescale:
+                pred = _nearest_zoom(pred, scale)
+            bufs = host_bufs.get(task_name)
+            if bufs is None or bufs[0].shape[1:] != pred.shape[1:] or bufs[0].shape[0] < pred.shape[0]:
+                shape = (max(int(full or 0), pred.shape[0]),) + tuple(pred.shape[1:])
+                bufs = host_bufs[task_name] = [torch.empty(shape, dtype=pred.dtype).pin_memory() for _ in range(2)]
+            buf = bufs[k & 1]
+            buf[:pred.shape[0]].copy_(pred, non_blocking=True)  # before the next replay overwrites the graph's output
+            done = torch.cuda.Event()
+            done.record()
+            host_preds[task_name] = (buf, done)
+        if pending is not None:
+            write_batch(*pending)
+        pending = (indices, host_preds)
+    if pending is not None:
+        write_batch(*pending)
     for dst in output_files.values():
         dst.close()
 

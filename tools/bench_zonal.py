@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--size", type=int, default=6048, help="raster height = width in pixels")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--profile", action="store_true", help="cProfile of the tile loop (host hot spots)")
+    ap.add_argument("--tif", action="store_true", help="also run from / to GeoTIFF files (built-in reader / writer)")
     args = ap.parse_args()
     from flairhip.configs import unet_resnet34_config
     from flair_hub.models.flair_model import FLAIR_HUB_Model
@@ -93,12 +95,44 @@ def main():
                                                                                      pin_memory=True)
     outputs, _ = zi.init_outputs(cfg2, ras)
     t.append(time.time())
+    if args.profile:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
     zi.inference_and_write(mdl, loader, tiles, cfg2, outputs, ras)
     torch.cuda.synchronize()
     t.append(time.time())
+    if args.profile:
+        pr.disable()
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
     names = ["config + slicing", "model build + checkpoint", "dataset + output rasters", "tile loop"]
     print("  stages: " + ", ".join(f"{n} {b - a:.2f} s" for n, a, b in zip(names, t, t[1:])) +
           f"  -> tile loop alone {len(tiles) / (t[4] - t[3]):.0f} tiles/s")
+
+    if args.tif:  # the same mosaic as an LZW GeoTIFF on disk, predictions written as GeoTIFF
+        import copy
+        import tempfile
+        from flair_zonal_detection.geotiff import GeoTiffWriter
+        d = tempfile.mkdtemp(prefix="bench_zonal_")
+        src = os.path.join(d, "mosaic.tif")
+        # label-like smooth content so that LZW has something to do (noise would not compress at all)
+        smooth = np.repeat(np.repeat(g.integers(0, 255, (5, H // 8 + 1, W // 8 + 1), dtype=np.uint8), 8, 1), 8, 2)[:, :H, :W]
+        for comp in ("lzw", None):
+            t0 = time.time()
+            with GeoTiffWriter.like(src, ras, 5, compress=comp) as w:
+                w.data[...] = smooth
+            t1 = time.time()
+            zt = copy.deepcopy(zc)
+            zt["modalities"][MOD]["input_img_path"] = src
+            zt["output_path"] = d
+            out = run_inference(zt)
+            torch.cuda.synchronize()
+            dt = time.time() - t1
+            print(f"GeoTIFF in ({comp or 'uncompressed'}, {os.path.getsize(src) / 1e6:.0f} MB, written in {t1 - t0:.1f} s) "
+                  f"-> GeoTIFF out ({os.path.getsize(out[TASK].path) / 1e6:.1f} MB): {dt:.2f} s = {ntiles / dt:.1f} tiles/s")
+        import shutil
+        shutil.rmtree(d)
 
 
 if __name__ == "__main__":
