@@ -590,14 +590,14 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
               const float r = (EB == 2) ? ffa_bf16_bits_to_f32(ffa_f32_to_bf16_bits(v[i])) : v[i];
               const float gg = (xv[i] * sc[i] + sh[i]) > 0.f ? r : 0.f;  // same fma as the forward / apply kernels
               st[g * 8 + i] += gg;
-              st[NCH + g * 8 + i] += gg * xv[i];
+              st[NCH + g * 8 + i] = __builtin_fmaf(gg, xv[i], st[NCH + g * 8 + i]);
             }
           } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               const float r = (EB == 2) ? ffa_bf16_bits_to_f32(ffa_f32_to_bf16_bits(v[i])) : v[i];
               st[g * 8 + i] += r;
-              st[NCH + g * 8 + i] += r * r;
+              st[NCH + g * 8 + i] = __builtin_fmaf(r, r, st[NCH + g * 8 + i]);  // explicit: both conv kernels must round alike
             }
           }
         }
@@ -635,10 +635,10 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
               const float xi = ffa_load_elem<T>(static_cast<const T*>(a.bnx) + pix + c0 + i);
               const float gg = (xi * a.bn_sc[c0 + i] + a.bn_sh[c0 + i]) > 0.f ? r : 0.f;
               st[g * 4 + i] += gg;
-              st[NCH + g * 4 + i] += gg * xi;
+              st[NCH + g * 4 + i] = __builtin_fmaf(gg, xi, st[NCH + g * 4 + i]);
             } else {
               st[g * 4 + i] += r;
-              st[NCH + g * 4 + i] += r * r;
+              st[NCH + g * 4 + i] = __builtin_fmaf(r, r, st[NCH + g * 4 + i]);
             }
           }
         }
@@ -701,8 +701,8 @@ __global__ void __launch_bounds__(64 * WCO * WPX, 2) conv_igemm_kernel(ConvArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Persistent variant of the pipelined 3x3 stride-1 path (opt-in: FFA_CONV_PERSIST=1; plain input, dil 1, no split /
-// bnbwd epilogue).  A block walks the virtual block list with stride gridDim.x and carries the software pipeline ACROSS
+// Persistent variant of the pipelined 3x3 stride-1 path (the default for plain input, dil 1, no split / bnbwd
+// epilogue; FFA_CONV_PERSIST=0 disables).  A block walks the virtual block list with stride gridDim.x and carries the software pipeline ACROSS
 // tiles: the next tile's halo and first two weight slabs are requested from inside the last chunk group of the
 // current tile and stored to LDS before the current tile's epilogue, so the prologue burst (35-40 % of a block's
 // life on the short-K layers, tools/conv_trace.py) and the epilogue's stores overlap matrix work instead of
@@ -984,7 +984,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_persist_kernel(ConvArgs a) {
               for (int i = 0; i < 8; ++i) {
                 const float r = (EB == 2) ? ffa_bf16_bits_to_f32(ffa_f32_to_bf16_bits(v[i])) : v[i];
                 st[g * 8 + i] += r;
-                st[NCH + g * 8 + i] += r * r;
+                st[NCH + g * 8 + i] = __builtin_fmaf(r, r, st[NCH + g * 8 + i]);  // explicit: both conv kernels must round alike
               }
             }
           } else {
@@ -1018,7 +1018,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_persist_kernel(ConvArgs a) {
               for (int i = 0; i < 4; ++i) {
                 const float r = (EB == 2) ? ffa_bf16_bits_to_f32(ffa_f32_to_bf16_bits(v[i])) : v[i];
                 st[g * 4 + i] += r;
-                st[NCH + g * 4 + i] += r * r;
+                st[NCH + g * 4 + i] = __builtin_fmaf(r, r, st[NCH + g * 4 + i]);
               }
             }
           }
@@ -1106,17 +1106,17 @@ static bool conv_supported(int kh, int kw, int stride, int bco) {
 }
 
 // Grid of the persistent 3x3 stride-1 kernel for a launch that would otherwise take `grid` one-tile blocks, or 0 for
-// the plain kernel.  Opt-in (FFA_CONV_PERSIST=1): measured -4...-9 % on the 64-channel 128^2 / 256^2 layers and
-// -0.1...-0.27 ms (0.7-1.7 %) per training step in same-box A/B runs, i.e. inside the box-to-box spread -- the
-// co-resident second block already hides most of a block's prologue, so the default stays the one-tile kernel and
-// the profiles keep one symbol per instantiation.  FFA_CONV_PERSIST_MIN / FFA_CONV_PERSIST_GRID move the threshold /
-// the grid (the tests force several tiles per block on small tensors).  Read per call: noise next to a launch.
+// the one-tile kernel.  On by default for every eligible launch (same-box A/B: 15.79 -> 15.50 ms per training step,
+// -4...-9 % on the 64-channel 128^2 / 256^2 layers whose grids need several dispatch rounds; a grid that fits one
+// round simply runs one tile per block).  FFA_CONV_PERSIST=0 restores conv_igemm_kernel everywhere;
+// FFA_CONV_PERSIST_MIN / FFA_CONV_PERSIST_GRID move the threshold / the grid (the tests force several tiles per
+// block on small tensors).  Read per call: a getenv is noise next to a launch.
 static int conv_persist_grid(int dil, int c1_out, const void* bnx, int grid) {
   const char* pe = getenv("FFA_CONV_PERSIST");
-  if (!(pe && pe[0] == '1') || dil != 1 || c1_out != 0 || bnx != nullptr) return 0;
+  if ((pe && pe[0] == '0') || dil != 1 || c1_out != 0 || bnx != nullptr) return 0;
   const char* pm = getenv("FFA_CONV_PERSIST_MIN");
   const char* pg = getenv("FFA_CONV_PERSIST_GRID");
-  const int min_grid = pm ? atoi(pm) : 512;
+  const int min_grid = pm ? atoi(pm) : 0;
   int pgrid = pg ? atoi(pg) : 512;
   pgrid = pgrid < 8 ? 8 : (pgrid / 8) * 8;  // whole groups of 8: a block keeps its XCD across tiles
   if (grid <= min_grid) return 0;

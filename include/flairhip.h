@@ -70,7 +70,7 @@ int ffa_conv2d(int dtype, const void* in, const void* w_packed, const float* bia
  * as called by smp's Conv2dReLU / torchvision's BasicBlock). */
 long long ffa_conv_stat_rows(int B, int Ho, int Wo);
 /* 1 when ffa_conv2d / ffa_conv2d_stats run this 3x3 stride-1 convolution on the persistent kernel
- * (conv3x3_persist_kernel, blocks that walk several pixel tiles; opt-in with FFA_CONV_PERSIST=1), else 0.
+ * (conv3x3_persist_kernel, blocks that walk several pixel tiles; FFA_CONV_PERSIST=0 disables), else 0.
  * Profiling aid: the two kernels are separate symbols. */
 int ffa_conv_is_persistent(int dtype, int B, int Ho, int Wo, int Ci, int co_rows, int bco, int kh, int kw, int stride,
                            int dil);
