@@ -187,9 +187,16 @@ class ArrayRaster(RasterBase):
             self.data[band - 1] = arr
             return
         c, r, w, h = int(window.col_off), int(window.row_off), int(window.width), int(window.height)
-        self.data[band - 1, r:r + h, c:c + w] = arr
+        arr = np.asarray(arr).reshape(h, w)
+        # The reference clips windows on the right / bottom only (inference.py:328-335); a raster smaller than one
+        # tile puts the clamped tile's kept area at a negative offset, which GDAL refuses.  Clip on every side here.
+        y0, x0 = max(-r, 0), max(-c, 0)
+        y1, x1 = min(h, self.height - r), min(w, self.width - c)
+        if y1 <= y0 or x1 <= x0:
+            return
+        self.data[band - 1, r + y0:r + y1, c + x0:c + x1] = arr[y0:y1, x0:x1]
         if self.written is not None:
-            self.written[r:r + h, c:c + w] = True
+            self.written[r + y0:r + y1, c + x0:c + x1] = True
 
     def close(self) -> None:
         self.closed = True
