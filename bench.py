@@ -315,12 +315,19 @@ def main():
                 sync = GradSync(task.model, broadcast_from_rank0=False)
     step = (lambda i: graphed(batch)) if use_graph else eager_step
 
+    if not use_graph:
+        # eager steps allocate (activations, gradients): let the caching allocator reach its steady state before the
+        # counted warm-up -- on some boxes the first ~15 eager steps ran at 23-25 ms (device-synchronising hipMalloc
+        # calls) against 15.5 afterwards; a graph replay owns its memory from the capture on and does not need this
+        for i in range(8):
+            eager_step(i)
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = not use_graph  # HIP events cannot time kernels inside a graph replay: see below
+    timer.enabled = False  # the timed region carries no instrumentation (events cannot see inside a replay anyway)
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
@@ -328,18 +335,16 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # roofline pass: the same step run eagerly a few times with HIP events around every MFMA kernel launch (all ranks
+    # take part: the eager step of a multi-process run contains the gradient all-reduce)
+    final_loss_t = loss.detach().clone()
+    roof_steps = 3
+    timer.enabled = True
+    for i in range(roof_steps):
+        eager_step(args.warmup + args.steps + i)
+    torch.cuda.synchronize()
     timer.enabled = False
-    roof_steps = args.steps
-    if use_graph:
-        # roofline pass: the same step run eagerly a few times with HIP events around every MFMA kernel launch
-        final_loss_t = loss.detach().clone()
-        roof_steps = 3
-        timer.enabled = True
-        for i in range(roof_steps):
-            eager_step(args.warmup + args.steps + i)
-        torch.cuda.synchronize()
-        timer.enabled = False
-        loss = final_loss_t
+    loss = final_loss_t
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
