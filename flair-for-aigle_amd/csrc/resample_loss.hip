@@ -167,48 +167,61 @@ __global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
   }
 }
 
+// Backward of the bilinear resize in GATHER form: one thread per 8 channels of a SOURCE pixel walks the destination
+// pixels whose footprint contains it (rows oy with y0(oy) == y or y1(oy) == y, same for columns; membership and
+// weights come from the very bilinear_src() the forward uses) and sums w_y * w_x * dy in a fixed order -- no atomics,
+// no f32 scratch image, reproducible bits.  The scatter form this replaces spent 2.5 ms per call (37 % of the
+// two-modality training step, tools/bench_fusion.py) in 64 contended f32 atomics per source value when
+// FusionHandler aligns a 4x coarser modality (flair_model.py:528-529).
 template <typename T>
-__global__ void bilinear_bwd_kernel(const T* __restrict__ dy, float* __restrict__ dx32, int B, int Hi, int Wi, int Ho,
+__global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int Hi, int Wi, int Ho,
                                     int Wo, int C, float sy, float sx) {
-  // scatter with f32 atomics into a zeroed f32 image (not on the U-Net@512 path, where the resize is
-  // the identity and is elided); converted to the storage dtype by bilinear_bwd_cast_kernel
   const int CG = C / 8;
-  const long long total = (long long)B * Ho * Wo * CG;
+  const long long total = (long long)B * Hi * Wi * CG;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int g = (int)(i % CG);
     long long p = i / CG;
-    const int ox = (int)(p % Wo);
-    p /= Wo;
-    const int oy = (int)(p % Ho);
-    const long long b = p / Ho;
-    int y0, y1, x0, x1;
-    float ly0, ly1, lx0, lx1;
-    bilinear_src(oy, sy, Hi, y0, y1, ly0, ly1);
-    bilinear_src(ox, sx, Wi, x0, x1, lx0, lx1);
-    float gv[8];
-    ffa_load8<T>(dy + i * 8, gv);
-    float* d00 = dx32 + ((b * Hi + y0) * Wi + x0) * C + g * 8;
-    float* d01 = dx32 + ((b * Hi + y0) * Wi + x1) * C + g * 8;
-    float* d10 = dx32 + ((b * Hi + y1) * Wi + x0) * C + g * 8;
-    float* d11 = dx32 + ((b * Hi + y1) * Wi + x1) * C + g * 8;
+    const int x = (int)(p % Wi);
+    p /= Wi;
+    const int y = (int)(p % Hi);
+    const long long b = p / Hi;
+    // destination rows / columns whose source coordinate lies within one pixel of (y, x), one extra on each side
+    // for the float rounding of the bounds; exact membership is decided per candidate below
+    int oy_lo = (int)floorf(((float)y - 0.5f) / sy - 0.5f) - 1, oy_hi = (int)ceilf(((float)y + 1.5f) / sy - 0.5f) + 1;
+    int ox_lo = (int)floorf(((float)x - 0.5f) / sx - 0.5f) - 1, ox_hi = (int)ceilf(((float)x + 1.5f) / sx - 0.5f) + 1;
+    oy_lo = oy_lo < 0 ? 0 : oy_lo;
+    ox_lo = ox_lo < 0 ? 0 : ox_lo;
+    oy_hi = oy_hi > Ho - 1 ? Ho - 1 : oy_hi;
+    ox_hi = ox_hi > Wo - 1 ? Wo - 1 : ox_hi;
+    float acc[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      atomicAdd(d00 + e, ly0 * lx0 * gv[e]);
-      atomicAdd(d01 + e, ly0 * lx1 * gv[e]);
-      atomicAdd(d10 + e, ly1 * lx0 * gv[e]);
-      atomicAdd(d11 + e, ly1 * lx1 * gv[e]);
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1;
+      float ly0, ly1;
+      bilinear_src(oy, sy, Hi, y0, y1, ly0, ly1);
+      const float wy = (y0 == y ? ly0 : 0.f) + (y1 == y ? ly1 : 0.f);  // y0 == y1 on the clamped last row
+      if (y0 != y && y1 != y) continue;
+      float row[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) row[e] = 0.f;
+      const T* drow = dy + ((b * Ho + oy) * Wo) * C + g * 8;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1;
+        float lx0, lx1;
+        bilinear_src(ox, sx, Wi, x0, x1, lx0, lx1);
+        if (x0 != x && x1 != x) continue;
+        const float wx = (x0 == x ? lx0 : 0.f) + (x1 == x ? lx1 : 0.f);
+        float gv[8];
+        ffa_load8<T>(drow + (long long)ox * C, gv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) row[e] += wx * gv[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += wy * row[e];
     }
-  }
-}
-
-template <typename T>
-__global__ void cast_from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, long long nvec) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec;
-       i += (long long)gridDim.x * blockDim.x) {
-    float v[8];
-    ffa_load8<float>(src + i * 8, v);
-    ffa_store8<T>(dst + i * 8, v);
+    ffa_store8<T>(dx + i * 8, acc);
   }
 }
 
@@ -226,37 +239,25 @@ extern "C" int ffa_bilinear_fwd(int dtype, const void* x, void* y, int B, int Hi
   return ffa_check_launch("bilinear_fwd");
 }
 
+// (kept in the ABI: earlier builds scattered into an f32 scratch image of this size; the gather-form backward needs
+// no workspace and accepts a null pointer)
 extern "C" long long ffa_bilinear_bwd_workspace_bytes(int B, int Hi, int Wi, int C) {
-  return (long long)B * Hi * Wi * C * sizeof(float);
+  (void)B; (void)Hi; (void)Wi; (void)C;
+  return 0;
 }
 
 extern "C" int ffa_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C,
                                 void* workspace, long long workspace_bytes, hipStream_t stream) {
-  FFA_REQUIRE(dy && dx && workspace && C % 8 == 0, "bilinear_bwd: bad arguments");
-  const long long need = ffa_bilinear_bwd_workspace_bytes(B, Hi, Wi, C);
-  if (workspace_bytes < need) {
-    ffa_set_error("bilinear_bwd: workspace too small");
-    return FFA_ERR_WORKSPACE;
-  }
-  hipError_t e = hipMemsetAsync(workspace, 0, need, stream);
-  if (e != hipSuccess) {
-    ffa_set_error("bilinear_bwd: memset failed: %s", hipGetErrorString(e));
-    return (int)e;
-  }
+  (void)workspace; (void)workspace_bytes;
+  FFA_REQUIRE(dy && dx && C % 8 == 0 && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "bilinear_bwd: bad arguments");
   const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
-  const long long items = (long long)B * Ho * Wo * (C / 8);
-  const long long nvec = (long long)B * Hi * Wi * (C / 8);
-  if (dtype == FFA_BF16) {
+  const long long items = (long long)B * Hi * Wi * (C / 8);
+  if (dtype == FFA_BF16)
     hipLaunchKernelGGL(bilinear_bwd_kernel<ffa_bf16>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
-                       (const ffa_bf16*)dy, (float*)workspace, B, Hi, Wi, Ho, Wo, C, sy, sx);
-    hipLaunchKernelGGL(cast_from_f32_kernel<ffa_bf16>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
-                       (const float*)workspace, (ffa_bf16*)dx, nvec);
-  } else {
+                       (const ffa_bf16*)dy, (ffa_bf16*)dx, B, Hi, Wi, Ho, Wo, C, sy, sx);
+  else
     hipLaunchKernelGGL(bilinear_bwd_kernel<float>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
-                       (const float*)dy, (float*)workspace, B, Hi, Wi, Ho, Wo, C, sy, sx);
-    hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
-                       (const float*)workspace, (float*)dx, nvec);
-  }
+                       (const float*)dy, (float*)dx, B, Hi, Wi, Ho, Wo, C, sy, sx);
   return ffa_check_launch("bilinear_bwd");
 }
 

@@ -560,9 +560,9 @@ def bilinear_bwd(dy: torch.Tensor, in_hw: Tuple[int, int]) -> torch.Tensor:
     B, Ho, Wo, C_ = dy.shape
     Hi, Wi = in_hw
     dx = torch.empty((B, Hi, Wi, C_), dtype=dy.dtype, device=dy.device)
-    ws = workspace(lib.ffa_bilinear_bwd_workspace_bytes(B, Hi, Wi, C_), dy.device, "bilinear")
-    _l.check(lib.ffa_bilinear_bwd(_dt(dy), dy.data_ptr(), dx.data_ptr(), B, Hi, Wi, Ho, Wo, C_, ws.data_ptr(),
-                                  ws.numel(), _stream()), "bilinear_bwd")
+    # gather-form backward: fixed summation order, no scratch image (the workspace arguments stay in the ABI)
+    _l.check(lib.ffa_bilinear_bwd(_dt(dy), dy.data_ptr(), dx.data_ptr(), B, Hi, Wi, Ho, Wo, C_, None, 0, _stream()),
+             "bilinear_bwd")
     return dx
 
 

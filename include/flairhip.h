@@ -14,8 +14,7 @@
  *     with the *_workspace_bytes functions)
  *   - tensors are raw device pointers, NHWC, contiguous, dtype FFA_BF16 (storage) or FFA_F32,
  *     channel pitch a multiple of 16 elements (8 where noted); pad channels must hold zeros
- *   - all reductions are fixed-order (bitwise reproducible); no float atomics except
- *     ffa_bilinear_bwd
+ *   - all reductions are fixed-order (bitwise reproducible); no float atomics anywhere
  */
 #ifndef FLAIRHIP_H
 #define FLAIRHIP_H
@@ -162,6 +161,8 @@ int ffa_upsample_nearest2x_concat_bwd(int dtype, const void* dcat, void* dlo, vo
                                       int C1, int C2, ffa_stream_t stream);
 int ffa_bilinear_fwd(int dtype, const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C,
                      ffa_stream_t stream);
+/* backward in gather form (each source value sums its destination footprint in a fixed order); the workspace
+ * arguments are kept for ABI stability: the query returns 0 and workspace may be null */
 long long ffa_bilinear_bwd_workspace_bytes(int B, int Hi, int Wi, int C);
 int ffa_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C,
                      void* workspace, long long workspace_bytes, ffa_stream_t stream);

@@ -327,7 +327,8 @@ def test_upsample_concat(cuda, dtype, C1, C2):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("hi,wi,ho,wo", [(16, 16, 64, 64), (24, 40, 24, 40), (13, 9, 40, 31), (32, 32, 10, 12)])
+@pytest.mark.parametrize("hi,wi,ho,wo", [(16, 16, 64, 64), (24, 40, 24, 40), (13, 9, 40, 31), (32, 32, 10, 12),
+                                         (1, 1, 8, 8), (2, 3, 17, 11), (64, 48, 3, 5), (8, 8, 32, 32)])
 def test_bilinear(cuda, dtype, hi, wi, ho, wo):
     from flairhip import ops
     g = torch.Generator().manual_seed(hi * wo)
@@ -342,6 +343,8 @@ def test_bilinear(cuda, dtype, hi, wi, ho, wo):
     torch.cuda.synchronize()
     assert (from_nhwc(y, C) - ref.detach()).abs().max().item() <= (2e-6 if dtype == torch.float32 else 0.04)
     assert (from_nhwc(dx, C) - xq.grad).abs().max().item() <= (2e-5 if dtype == torch.float32 else 0.1)
+    # gather-form backward: fixed summation order, so a second run gives the same bits (no atomics)
+    assert torch.equal(ops.bilinear_bwd(to_nhwc(dy, dtype, cuda), (hi, wi)), dx)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
