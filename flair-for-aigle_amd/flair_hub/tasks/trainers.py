@@ -32,6 +32,43 @@ def _to_device(batch: dict, device) -> dict:
     return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
 
+class DevicePrefetcher:
+    """Host batches -> device batches, one batch ahead on a copy stream: while the device runs step k the host fetches
+    batch k+1 from the loader and its H2D copy proceeds next to the compute kernels (the reference schema moves 25 MB
+    per tile -- f32 imagery + f32 one-hot labels -- i.e. ~15 ms of PCIe time per 32-tile batch, as long as the step
+    itself).  Pinned loader output (DataLoader(pin_memory=True)) makes the copies asynchronous; pageable tensors
+    still work, their copies just block the host."""
+
+    def __init__(self, loader: Iterable, device: torch.device):
+        self.loader, self.device = loader, device
+        self.stream = torch.cuda.Stream(device)
+
+    def __len__(self) -> int:
+        return len(self.loader)
+
+    def _stage(self, host: Optional[dict]):
+        if host is None:
+            return None
+        with torch.cuda.stream(self.stream):
+            dev = _to_device(host, self.device)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        return dev, done
+
+    def __iter__(self):
+        it = iter(self.loader)
+        cur = self._stage(next(it, None))
+        while cur is not None:
+            batch, done = cur
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(done)
+            for v in batch.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(main)  # allocated on the copy stream, consumed on the compute stream
+            yield batch  # the consumer enqueues step k and comes back for more
+            cur = self._stage(next(it, None))  # fetch + copy of batch k+1 overlap step k on the device
+
+
 class HipTrainer:
     """The subset of pytorch_lightning.Trainer the reference relies on."""
 
@@ -86,8 +123,7 @@ class HipTrainer:
         graphed, graph_sig, loss = None, None, None
         for epoch in range(self.max_epochs):
             model.train()
-            for i, batch in enumerate(train_dataloaders):
-                batch = _to_device(batch, self.device)
+            for i, batch in enumerate(DevicePrefetcher(train_dataloaders, self.device)):
                 if use_graph and graphed is None and model.global_step >= 2:
                     # two ordinary steps first: they size every workspace, fill the weight-pack plan and create the
                     # optimizer state, so the capture itself needs no warm-up steps that would move the weights
