@@ -115,12 +115,13 @@ extern "C" int ffa_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, i
   return ffa_check_launch("nchw_to_nhwc");
 }
 
-// uint8 NCHW raster tiles -> normalised NHWC compute tensor in one pass: dst = (src - mean[c]) / std[c] (the 'custom'
-// normalisation of flair_hub/data/utils_data/norm.py:37-44; 'scaling' is mean 0, std 255).  The zonal loop then ships
-// 1 byte per input sample over PCIe instead of 4 and does no per-tile float work on the host.
-template <typename T>
-__global__ void u8_nchw_to_nhwc_kernel(const uint8_t* __restrict__ src, T* __restrict__ dst, int B, int C, int H, int W,
-                                       int Cp, const float* __restrict__ mean, const float* __restrict__ stdv) {
+// Raw NCHW raster tiles (uint8 / uint16 / int16 / float32 samples) -> normalised NHWC compute tensor in one pass:
+// dst = (src - mean[c]) / std[c] (the 'custom' normalisation of flair_hub/data/utils_data/norm.py:37-44; 'scaling' is
+// mean 0, std 255).  The zonal loop then ships the raster's own sample size over PCIe (1 byte for the aerial
+// mosaics) instead of 4 and does no per-tile float work on the host.
+template <typename S, typename T>
+__global__ void raw_nchw_to_nhwc_kernel(const S* __restrict__ src, T* __restrict__ dst, int B, int C, int H, int W,
+                                        int Cp, const float* __restrict__ mean, const float* __restrict__ stdv) {
   const int groups = Cp / 8;
   const long long hw = (long long)H * W;
   const long long total = (long long)B * hw * groups;
@@ -139,17 +140,39 @@ __global__ void u8_nchw_to_nhwc_kernel(const uint8_t* __restrict__ src, T* __res
   }
 }
 
+template <typename S>
+static int raw_layout_launch(int dtype, const void* src, void* dst, int B, int C, int H, int W, int Cp,
+                             const float* mean, const float* stdv, hipStream_t stream) {
+  const long long items = (long long)B * H * W * (Cp / 8);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL((raw_nchw_to_nhwc_kernel<S, ffa_bf16>), dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const S*)src, (ffa_bf16*)dst, B, C, H, W, Cp, mean, stdv);
+  else
+    hipLaunchKernelGGL((raw_nchw_to_nhwc_kernel<S, float>), dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+                       (const S*)src, (float*)dst, B, C, H, W, Cp, mean, stdv);
+  return ffa_check_launch("raw_nchw_to_nhwc");
+}
+
 extern "C" int ffa_u8_nchw_to_nhwc(int dtype, const uint8_t* src, void* dst, int B, int C, int H, int W, int Cp,
                                    const float* mean, const float* stdv, hipStream_t stream) {
   FFA_REQUIRE(src && dst && mean && stdv && Cp % 8 == 0 && Cp >= C, "u8_nchw_to_nhwc: bad arguments (C=%d Cp=%d)", C, Cp);
-  const long long items = (long long)B * H * W * (Cp / 8);
-  if (dtype == FFA_BF16)
-    hipLaunchKernelGGL(u8_nchw_to_nhwc_kernel<ffa_bf16>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream, src,
-                       (ffa_bf16*)dst, B, C, H, W, Cp, mean, stdv);
-  else
-    hipLaunchKernelGGL(u8_nchw_to_nhwc_kernel<float>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream, src,
-                       (float*)dst, B, C, H, W, Cp, mean, stdv);
-  return ffa_check_launch("u8_nchw_to_nhwc");
+  return raw_layout_launch<uint8_t>(dtype, src, dst, B, C, H, W, Cp, mean, stdv, stream);
+}
+
+// The same for the other sample types rasters come in: src_kind FFA_SRC_U8 (0), FFA_SRC_U16 (1: SPOT, Sentinel
+// reflectances), FFA_SRC_I16 (2), FFA_SRC_F32 (3: elevation models).
+extern "C" int ffa_raw_nchw_to_nhwc(int dtype, int src_kind, const void* src, void* dst, int B, int C, int H, int W,
+                                    int Cp, const float* mean, const float* stdv, hipStream_t stream) {
+  FFA_REQUIRE(src && dst && mean && stdv && Cp % 8 == 0 && Cp >= C, "raw_nchw_to_nhwc: bad arguments (C=%d Cp=%d)", C,
+              Cp);
+  switch (src_kind) {
+    case 0: return raw_layout_launch<uint8_t>(dtype, src, dst, B, C, H, W, Cp, mean, stdv, stream);
+    case 1: return raw_layout_launch<uint16_t>(dtype, src, dst, B, C, H, W, Cp, mean, stdv, stream);
+    case 2: return raw_layout_launch<int16_t>(dtype, src, dst, B, C, H, W, Cp, mean, stdv, stream);
+    case 3: return raw_layout_launch<float>(dtype, src, dst, B, C, H, W, Cp, mean, stdv, stream);
+  }
+  ffa_set_error("raw_nchw_to_nhwc: unknown source sample kind %d", src_kind);
+  return FFA_ERR_ARG;
 }
 
 extern "C" int ffa_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H, int W, int Cp,

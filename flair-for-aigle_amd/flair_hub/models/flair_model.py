@@ -166,9 +166,9 @@ class FLAIR_HUB_Model(nn.Module):
         return hnn.bilinear(x, hw)
 
     def _input_nhwc(self, x: torch.Tensor, mod: str, norm=None) -> torch.Tensor:
-        """batch tensor -> NHWC compute tensor.  Besides the reference's normalised f32 [B,C,H,W] tensors, raw uint8
-        tiles are accepted when the batch carries '<MOD>_NORM' = f32 [2,C] (mean, std): the zonal dataset's
-        (x - mean) / std then happens in the layout kernel on the device."""
+        """batch tensor -> NHWC compute tensor.  Besides the reference's normalised f32 [B,C,H,W] tensors, raw raster
+        samples (uint8 / uint16 / int16 / float32) are accepted when the batch carries '<MOD>_NORM' = f32 [2,C]
+        (mean, std): the zonal dataset's (x - mean) / std then happens in the layout kernel on the device."""
         enc = self.encoders[mod].seg_model
         if x.ndim != 4 or x.shape[1] != enc.in_channels:
             raise ValueError(f"batch['{mod}'] must be [B,{enc.in_channels},H,W], got {tuple(x.shape)}")
@@ -176,12 +176,16 @@ class FLAIR_HUB_Model(nn.Module):
             raise RuntimeError(f"input height and width must be divisible by 32, got {tuple(x.shape[-2:])}")
         if not x.is_cuda:
             raise RuntimeError("FLAIR_HUB_Model (libflairhip) runs on an MI355X only: move the batch to cuda")
-        if x.dtype == torch.uint8:
+        if x.dtype != torch.float32 or norm is not None:
+            # raw raster samples (uint8 / uint16 / int16, or float32 next to a '<MOD>_NORM' entry)
             if norm is None:
-                raise ValueError(f"batch['{mod}'] is uint8: batch['{mod}_NORM'] (f32 [2,C]: mean, std) is required")
+                raise ValueError(f"batch['{mod}'] is {x.dtype}: batch['{mod}_NORM'] (f32 [2,C]: mean, std) is required")
             norm = norm.to(x.device, torch.float32)
-            return ops.u8_nchw_to_nhwc(x.contiguous(), self.compute_dtype, norm[0].contiguous(), norm[1].contiguous(),
-                                       ops.pad_channels(enc.in_channels))
+            if x.dtype == torch.uint8:
+                return ops.u8_nchw_to_nhwc(x.contiguous(), self.compute_dtype, norm[0].contiguous(),
+                                           norm[1].contiguous(), ops.pad_channels(enc.in_channels))
+            return ops.raw_nchw_to_nhwc(x.contiguous(), self.compute_dtype, norm[0].contiguous(), norm[1].contiguous(),
+                                        ops.pad_channels(enc.in_channels))
         return hnn.to_nhwc(x, self.compute_dtype, ops.pad_channels(enc.in_channels))
 
     def modality_dropout(self, feature_maps: Dict[str, list], modalities_dropout_dict: Dict[str, float]):

@@ -38,6 +38,11 @@ def normalize_array(img: np.ndarray, norm_type, means, stds) -> np.ndarray:
     return img
 
 
+# sample types the layout kernel normalises on the device (ffa_u8_nchw_to_nhwc / ffa_raw_nchw_to_nhwc)
+RAW_DTYPES = {np.dtype(np.uint8): torch.uint8, np.dtype(np.uint16): torch.uint16, np.dtype(np.int16): torch.int16,
+              np.dtype(np.float32): torch.float32}
+
+
 class MultiModalSlicedDataset(Dataset):
     def __init__(self, dataframe, modality_cfgs: Dict[str, Dict[str, Any]], patch_size_dict: Dict[str, int],
                  ref_date_str: str, modalities_config: Dict[str, Any], reference_batch_schema: bool = False,
@@ -72,6 +77,18 @@ class MultiModalSlicedDataset(Dataset):
         return reader.read(indexes=cfg["channels"], window=window, out_shape=(len(cfg["channels"]), patch_size,
                            patch_size), resampling=Resampling.bilinear, boundless=True, fill_value=0)
 
+    def delivers_raw(self, mod: str) -> bool:
+        """True when tiles of ``mod`` leave this dataset as raw raster samples (+ '<MOD>_NORM' rides along in the loop)"""
+        if not self.device_normalize or self.norm_vectors(mod) is None:
+            return False
+        dt = getattr(self.readers[mod], "dtype", None)
+        if dt is None and hasattr(self.readers[mod], "dtypes"):  # rasterio dataset
+            dt = self.readers[mod].dtypes[0]
+        try:
+            return np.dtype(dt).newbyteorder("=") in RAW_DTYPES
+        except TypeError:
+            return False
+
     def norm_vectors(self, mod: str):
         """(mean, std) per channel of the normalisation the device applies to uint8 tiles of ``mod``, or None"""
         cfg = self.modalities[mod]
@@ -92,8 +109,8 @@ class MultiModalSlicedDataset(Dataset):
         for mod, cfg in self.modalities.items():
             patch = self._load_patch(self.readers[mod], bounds, cfg, self.patch_sizes[mod])
             ncfg = cfg.get("normalization", {})
-            if self.device_normalize and patch.dtype == np.uint8 and self.norm_vectors(mod) is not None:
-                out[mod] = torch.from_numpy(np.ascontiguousarray(patch))
+            if self.device_normalize and patch.dtype in RAW_DTYPES and self.norm_vectors(mod) is not None:
+                out[mod] = torch.from_numpy(np.ascontiguousarray(patch))  # raw samples: the device normalises
                 continue
             norm = normalize_array(patch, ncfg.get("type"), ncfg.get("means"), ncfg.get("stds")) if ncfg else patch
             out[mod] = torch.tensor(np.ascontiguousarray(norm), dtype=torch.float32)
@@ -109,7 +126,8 @@ class MultiModalSlicedDataset(Dataset):
 
 
 class TileBatcher:
-    """Batches of raw uint8 tiles for the zonal loop, written by the raster reader straight into reused pinned host
+    """Batches of raw raster tiles (uint8, or uint16 / int16 / float32) for the zonal loop, written by the raster reader
+    straight into reused pinned host
     buffers: no per-tile tensor, no collate copy, no pin copy (torch's default DataLoader path spent 60 % of the
     loop's wall time in torch.stack and pandas row lookups).  Needs a dataset in device_normalize mode whose
     rasters read uint8 and accept ``read_bounds(..., out=)``; use ``TileBatcher.supports(dataset)``.
@@ -122,7 +140,8 @@ class TileBatcher:
 
     def __init__(self, dataset: MultiModalSlicedDataset, batch_size: int, prefetch: bool = True):
         if not self.supports(dataset):
-            raise ValueError("TileBatcher needs device_normalize uint8 rasters with read_bounds(..., out=)")
+            raise ValueError("TileBatcher needs device_normalize rasters of uint8 / uint16 / int16 / float32 samples "
+                             "with read_bounds(..., out=)")
         self.ds = self.dataset = dataset
         self.bs = self.batch_size = int(batch_size)
         self.prefetch = bool(prefetch)  # read (and decode) the next batch on a worker thread while the device runs
@@ -130,8 +149,9 @@ class TileBatcher:
         self.bufs = {}
         for mod, cfg in dataset.modalities.items():
             shape = (self.bs, len(cfg["channels"]), dataset.patch_sizes[mod], dataset.patch_sizes[mod])
-            self.bufs[mod] = [torch.empty(shape, dtype=torch.uint8).pin_memory() if torch.cuda.is_available()
-                              else torch.empty(shape, dtype=torch.uint8) for _ in range(self.NBUF)]
+            tdt = RAW_DTYPES[np.dtype(dataset.readers[mod].dtype).newbyteorder("=")]
+            self.bufs[mod] = [torch.empty(shape, dtype=tdt).pin_memory() if torch.cuda.is_available()
+                              else torch.empty(shape, dtype=tdt) for _ in range(self.NBUF)]
 
     @staticmethod
     def supports(dataset) -> bool:
@@ -140,7 +160,7 @@ class TileBatcher:
         for mod, reader in dataset.readers.items():
             if dataset.norm_vectors(mod) is None or not hasattr(reader, "read_bounds"):
                 return False
-            if np.dtype(getattr(reader, "dtype", None) or object) != np.uint8:  # ArrayRaster / GeoTiffRaster of bytes
+            if not dataset.delivers_raw(mod) or getattr(reader, "dtype", None) is None:  # ArrayRaster / GeoTiffRaster
                 return False
         return True
 

@@ -190,14 +190,13 @@ def inference_and_write(model: torch.nn.Module, dataloader: DataLoader, tiles_gd
     img_bounds = tuple(ref_img.bounds)  # (left, bottom, right, top)
     keep = tile_size - 2 * margin
 
-    # uint8 tiles (dataset with device_normalize): the per-channel (mean, std) ride along once per modality
+    # raw raster tiles (dataset with device_normalize): the per-channel (mean, std) ride along once per modality
     norms = {}
     ds = getattr(dataloader, "dataset", None)
     if getattr(ds, "device_normalize", False):
         for mod in ds.modalities:
-            nv = ds.norm_vectors(mod)
-            if nv is not None:
-                norms[mod + "_NORM"] = torch.tensor(np.stack(nv), dtype=torch.float32, device=device)
+            if ds.delivers_raw(mod):
+                norms[mod + "_NORM"] = torch.tensor(np.stack(ds.norm_vectors(mod)), dtype=torch.float32, device=device)
 
     # tile columns as plain arrays: a pandas row lookup costs ~0.5 ms, twice per tile
     lefts, tops, ids = (np.asarray(tiles_gdf[c]) for c in ("left", "top", "id"))
@@ -242,7 +241,7 @@ def inference_and_write(model: torch.nn.Module, dataloader: DataLoader, tiles_gd
         inputs = {k_: v.to(device, non_blocking=True) for k_, v in batch.items()
                   if k_ != "index" and torch.is_tensor(v)}
         for k_, v in norms.items():
-            if inputs.get(k_[:-5]) is not None and inputs[k_[:-5]].dtype == torch.uint8:
+            if inputs.get(k_[:-5]) is not None:
                 inputs[k_] = v
         indices = batch["index"].cpu().numpy().flatten()
         if use_graph and full and len(indices) == full:

@@ -101,7 +101,8 @@ class RasterBase:
                 at(y0 + 1, x0) * fy * (1 - fx) + at(y0 + 1, x0 + 1) * fy * fx)
         res_ = out_.astype(dtype) if np.issubdtype(dtype, np.floating) else out_
         if out is not None:
-            out[...] = res_
+            # integer destination: round to nearest like GDAL's resampler (a plain cast would truncate)
+            out[...] = res_ if np.issubdtype(out.dtype, np.floating) else np.rint(res_)
             return out
         return res_
 

@@ -71,6 +71,7 @@ SIGNATURES = {
     "ffa_maxpool3x3s2_bwd": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "ffa_nchw_to_nhwc": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ffa_u8_nchw_to_nhwc": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "ffa_raw_nchw_to_nhwc": (_i, [_i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "ffa_nhwc_to_nchw": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ffa_upsample_nearest2x_concat_fwd": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ffa_upsample_nearest2x_concat_bwd": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -504,6 +504,27 @@ def u8_nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, mean: torch.Tensor, std
     return out
 
 
+RAW_SAMPLE_KINDS = {torch.uint8: 0, torch.uint16: 1, torch.int16: 2, torch.float32: 3}  # FFA_SRC_*
+
+
+def raw_nchw_to_nhwc(x: torch.Tensor, dtype: torch.dtype, mean: torch.Tensor, std: torch.Tensor,
+                     cp: Optional[int] = None) -> torch.Tensor:
+    """raw raster samples (uint8 / uint16 / int16 / float32) [B,C,H,W] -> NHWC compute tensor holding
+    (x - mean[c]) / std[c]; mean / std f32 device vectors [C]"""
+    lib = _l.load()
+    if x.dtype not in RAW_SAMPLE_KINDS or x.ndim != 4 or not x.is_contiguous():
+        raise ValueError(f"raw_nchw_to_nhwc: contiguous [B,C,H,W] of uint8 / uint16 / int16 / float32 expected, "
+                         f"got {x.dtype} {tuple(x.shape)}")
+    B, C_, H, W = x.shape
+    if mean.numel() < C_ or std.numel() < C_ or mean.dtype != torch.float32 or std.dtype != torch.float32:
+        raise ValueError("raw_nchw_to_nhwc: mean / std must be f32 vectors with one entry per channel")
+    cp = pad_channels(C_) if cp is None else cp
+    out = torch.empty((B, H, W, cp), dtype=dtype, device=x.device)
+    _l.check(lib.ffa_raw_nchw_to_nhwc(_dtype_id(dtype), RAW_SAMPLE_KINDS[x.dtype], x.data_ptr(), out.data_ptr(), B, C_,
+                                      H, W, cp, mean.data_ptr(), std.data_ptr(), _stream()), "raw_nchw_to_nhwc")
+    return out
+
+
 def nhwc_to_nchw(x: torch.Tensor, channels: int) -> torch.Tensor:
     lib = _l.load()
     _chk_nhwc(x, "nhwc_to_nchw input")

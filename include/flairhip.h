@@ -151,6 +151,14 @@ int ffa_nchw_to_nhwc(int dtype, const float* src, void* dst, int B, int C, int H
  * flair_hub/data/utils_data/norm.py:37-44 reached from flair_zonal_detection/dataset.py:174-209, done on the device) */
 int ffa_u8_nchw_to_nhwc(int dtype, const uint8_t* src, void* dst, int B, int C, int H, int W, int Cp,
                         const float* mean, const float* stdv, ffa_stream_t stream);
+/* the same pass for the other sample types rasters come in (uint16 SPOT / Sentinel reflectances, int16, float32
+ * elevation models): dst = (src - mean[c]) / std[c] */
+#define FFA_SRC_U8 0
+#define FFA_SRC_U16 1
+#define FFA_SRC_I16 2
+#define FFA_SRC_F32 3
+int ffa_raw_nchw_to_nhwc(int dtype, int src_kind, const void* src, void* dst, int B, int C, int H, int W, int Cp,
+                         const float* mean, const float* stdv, ffa_stream_t stream);
 int ffa_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, int C, int H, int W, int Cp, ffa_stream_t stream);
 
 /* ---- decoder resampling (smp DecoderBlock nearest x2 + cat; flair_model.py:318-327 interpolate_map) */

@@ -593,6 +593,35 @@ def test_u8_tiles_normalised_by_the_layout_kernel(cuda, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("src", [torch.uint8, torch.uint16, torch.int16, torch.float32], ids=["u8", "u16", "i16", "f32src"])
+def test_raw_raster_samples_normalised_by_the_layout_kernel(cuda, dtype, src):
+    """ffa_raw_nchw_to_nhwc for the sample types rasters come in (uint16 SPOT / Sentinel, int16, float32 elevation):
+    (x - mean) / std as the dataset computes it (norm.py:37-44), pad channels zero"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(9)
+    shape = (2, 3, 24, 40)
+    if src == torch.float32:
+        x = torch.randn(shape, generator=g) * 300 + 800
+    else:
+        lo, hi = {torch.uint8: (0, 256), torch.uint16: (0, 65536), torch.int16: (-32768, 32768)}[src]
+        x = torch.from_numpy(np.random.default_rng(9).integers(lo, hi, shape).astype(
+            {torch.uint8: np.uint8, torch.uint16: np.uint16, torch.int16: np.int16}[src]))
+    mean = torch.tensor([1137.03, 433.26, 467.77])
+    std = torch.tensor([543.11, 312.76, 284.61])
+    xd = torch.from_numpy(x.numpy().astype(np.float64))
+    ref = ((xd - mean.double()[None, :, None, None]) / std.double()[None, :, None, None]).float()
+    want = ops.nchw_to_nhwc(ref.to(cuda), dtype, 16)
+    got = ops.raw_nchw_to_nhwc(x.to(cuda), dtype, mean.to(cuda), std.to(cuda), 16)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape and float(got[..., 3:].float().abs().max()) == 0.0
+    scale = max(1.0, float(ref.abs().max()))
+    tol = 2e-6 if dtype == torch.float32 else 2 ** -7
+    assert (got.float() - want.float()).abs().max().item() <= tol * scale
+    with pytest.raises(ValueError):
+        ops.raw_nchw_to_nhwc(x.double().to(cuda), dtype, mean.to(cuda), std.to(cuda), 16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("cin,cout,H,W,grid", [
     (64, 64, 40, 72, 8),      # bf16: one group of four chunks per tile (every halo crosses tiles); 2 tiles / block
     (128, 64, 33, 70, 16),    # two groups per tile, ragged tiles
