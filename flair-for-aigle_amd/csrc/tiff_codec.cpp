@@ -28,12 +28,24 @@ struct BitReader {
   const uint8_t* end;
   uint64_t acc = 0;
   int have = 0;
-  // next `bits`-wide code, or -1 when the stream is exhausted
-  int get(int bits) {
-    while (have < bits) {
-      if (p == end) return -1;
-      acc = (acc << 8) | *p++;
-      have += 8;
+  // next `bits`-wide code (bits <= 12), or -1 when the stream is exhausted
+  inline int get(int bits) {
+    if (have < bits) {
+      if (end - p >= 8) {  // refill up to 56 bits with one unaligned big-endian load
+        uint64_t w;
+        memcpy(&w, p, 8);
+        w = __builtin_bswap64(w);
+        const int take = (64 - have) >> 3;  // whole bytes that fit
+        acc = (take == 8) ? w : ((acc << (8 * take)) | (w >> (64 - 8 * take)));
+        have += 8 * take;
+        p += take;
+      } else {
+        while (have < bits) {
+          if (p == end) return -1;
+          acc = (acc << 8) | *p++;
+          have += 8;
+        }
+      }
     }
     have -= bits;
     return (int)((acc >> have) & ((1u << bits) - 1));
@@ -123,7 +135,15 @@ extern "C" long long ffa_tiff_lzw_decode(const uint8_t* src, long long n, uint8_
       len = length[code];
       const uint8_t* from = dst + where[code];  // written earlier in full (where + len <= out): no overlap
       const long long m = (out + len <= cap) ? len : cap - out;
-      if (m <= 16) {
+      if (out + 16 <= cap && len <= 16 && where[code] + 16 <= out) {
+        // short string away from the write position and from the end of the buffer: two blind 8-byte moves (the
+        // bytes past `len` are overwritten by the next code)
+        uint64_t a, b;
+        memcpy(&a, from, 8);
+        memcpy(&b, from + 8, 8);
+        memcpy(dst + out, &a, 8);
+        memcpy(dst + out + 8, &b, 8);
+      } else if (m <= 16) {
         for (long long i = 0; i < m; ++i) dst[out + i] = from[i];
       } else {
         memcpy(dst + out, from, (size_t)m);

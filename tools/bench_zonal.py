@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--size", type=int, default=6048, help="raster height = width in pixels")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--output-type", default="argmax", choices=["argmax", "class_prob"])
     ap.add_argument("--profile", action="store_true", help="cProfile of the tile loop (host hot spots)")
     ap.add_argument("--tif", action="store_true", help="also run from / to GeoTIFF files (built-in reader / writer)")
     args = ap.parse_args()
@@ -62,7 +63,7 @@ def main():
     ras = ArrayRaster(img, 651000.0, 6865000.0, 0.2)
     zc = yaml.safe_load(open(os.path.join(ROOT, "tests", "golden", "zonal_config.yaml")))
     zc.update({"output_path": "/tmp", "output_name": "bench_zonal", "img_pixels_detection": 512, "margin": 40,
-               "output_px_meters": 0.2, "output_type": "argmax", "batch_size": args.batch, "num_worker": 0,
+               "output_px_meters": 0.2, "output_type": args.output_type, "batch_size": args.batch, "num_worker": 0,
                "hardware": {"precision": args.precision}, "model_weights": "/tmp/bench_zonal_weights.ckpt",
                "monotemp_arch": "resnet34-unet"})
     torch.save({"state_dict": {"model." + k: v.cpu() for k, v in model.state_dict().items()}}, zc["model_weights"])
