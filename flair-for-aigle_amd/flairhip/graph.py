@@ -67,6 +67,9 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
         pending = [bn._pending_batches for bn in self._bns]
+        # every packed operand counts as stale from here: the pack kernels MUST be part of the captured step (a plan
+        # that happens to be fresh at capture time would otherwise leave the replays training on frozen operands)
+        hnn.bump_state_epoch()
         with torch.cuda.graph(self.graph):
             loss = task.training_step(self.static_batch, 0)
             loss.backward()
@@ -98,6 +101,9 @@ class GraphedTrainStep:
                 if dst.data_ptr() != v.data_ptr():
                     dst.copy_(v, non_blocking=True)
         self.graph.replay()
+        # weights and BatchNorm statistics moved on the device behind Python's back: version-keyed caches (packed
+        # operands used by eager steps, eval-mode BatchNorm folds used by validation) must not survive the replay
+        hnn.bump_state_epoch()
         if self.grad_reduce is not None:
             self.grad_reduce(self.params, self.static_grads)
             self.optimizer.step()

@@ -48,7 +48,7 @@ class HipConv2d(nn.Module):
                tag: str = "") -> ops.PackedWeight:
         """MFMA operand for the current weight values; re-packed only when the parameter changed."""
         key = (dtype, transpose, tag)
-        ver = (self.weight._version, self.weight.data_ptr(), None if scale is None else scale._version)
+        ver = (self.weight._version, self.weight.data_ptr(), None if scale is None else scale._version, _STATE_EPOCH)
         hit = self._cache.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
@@ -63,6 +63,34 @@ class HipConv2d(nn.Module):
     def extra_repr(self) -> str:
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
                 f"padding={self.padding}, bias={self.bias is not None}")
+
+
+_STATE_EPOCH = 0
+
+
+def state_epoch() -> int:
+    return _STATE_EPOCH
+
+
+def bump_state_epoch() -> None:
+    """Parameters / buffers changed on the device without Python noticing (a hipGraph replay runs the optimizer and
+    the BatchNorm running-statistics updates in place: no tensor ``_version`` moves).  Every cache keyed on versions
+    -- packed MFMA operands, eval-mode BatchNorm folds -- carries this epoch as well and is rebuilt on next use."""
+    global _STATE_EPOCH
+    _STATE_EPOCH += 1
+
+
+def _after_optimizer_step(optimizer, args, kwargs) -> None:
+    bump_state_epoch()
+
+
+# torch's fused (single-kernel) Adam / AdamW / SGD update parameters WITHOUT moving their ``_version`` (checked on
+# torch 2.10: fused=True leaves p._version unchanged, the foreach / single-tensor paths bump it), so a cache keyed on
+# versions alone would keep feeding the convolutions the weights of the first step.  Every optimizer step in the
+# process therefore advances the state epoch.
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
+
+_register_step_hook(_after_optimizer_step)
 
 
 class PackPlan:
@@ -94,13 +122,13 @@ class PackPlan:
                 return
             self.batch, self.sig, self.versions = ops.PackBatch(entries, dtype), sig, None
         stale = [i for i, (c, tr) in enumerate(slots)
-                 if c._cache[(dtype, tr, "")][0][0] != versions[i]]
+                 if c._cache[(dtype, tr, "")][0][0] != versions[i] or c._cache[(dtype, tr, "")][0][3] != _STATE_EPOCH]
         if not stale:
             return
         self.batch.run()
         for (c, tr), v in zip(slots, versions):
             key = (dtype, tr, "")
-            c._cache[key] = ((v, c.weight.data_ptr(), None), c._cache[key][1])
+            c._cache[key] = ((v, c.weight.data_ptr(), None, _STATE_EPOCH), c._cache[key][1])
 
 
 class HipBatchNorm2d(nn.Module):
@@ -528,7 +556,7 @@ def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, relu: bool = True, resid
 def _eval_folded(conv: HipConv2d, bn: HipBatchNorm2d, dtype: torch.dtype):
     """(packed weights with the eval-mode BatchNorm scale folded in, shift vector), cached per parameter version"""
     ver = (conv.weight._version, conv.weight.data_ptr(), bn.weight._version, bn.bias._version,
-           bn.running_mean._version, bn.running_var._version, dtype)
+           bn.running_mean._version, bn.running_var._version, dtype, _STATE_EPOCH)
     hit = conv._cache.get("eval_fold")
     if hit is None or hit[0] != ver:
         scale, shift = ops.bn_eval_params(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,

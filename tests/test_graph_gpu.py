@@ -119,3 +119,41 @@ def test_graph_plus_bucket_reduce_equals_the_eager_step(cuda):
     le, we = run(False)
     lg, wg = run(True)
     assert le == lg and torch.equal(we, wg)
+
+
+def test_eval_after_graph_replays_uses_the_trained_weights(cuda):
+    """a replay moves weights and BatchNorm statistics on the device without touching any tensor version: caches
+    keyed on versions (packed operands, eval-mode BatchNorm folds) must be rebuilt -- the eval forward after graph
+    training equals the eval forward of a fresh model loaded with the trained state dict, and an eager training step
+    after replays equals the same step on that fresh model"""
+    from flairhip.graph import GraphedTrainStep
+    from helpers import make_pair
+    task, _, _ = make_pair(precision="bf16")
+    g = torch.Generator().manual_seed(23)
+    batch = {MOD: torch.randn(4, 5, 64, 64, generator=g).to(cuda),
+             TASK: torch.randint(0, 19, (4, 64, 64), generator=g).to(torch.uint8).to(cuda)}
+    task.eval()
+    with torch.no_grad():
+        before = task.model(batch)[0][TASK].clone()  # fills the eval-fold caches with the initial weights
+    task.train()
+    opt = torch.optim.AdamW(task.model.parameters(), lr=1e-2, fused=True)
+    graphed = GraphedTrainStep(task, opt, batch, warmup_steps=2)
+    for _ in range(5):
+        graphed(batch)
+    torch.cuda.synchronize()
+    task.eval()
+    with torch.no_grad():
+        after = task.model(batch)[0][TASK].clone()
+    fresh, _, _ = make_pair(precision="bf16", seed=99)  # other initial weights, then the trained state
+    fresh.model.load_state_dict(task.model.state_dict())
+    fresh.eval()
+    with torch.no_grad():
+        want = fresh.model(batch)[0][TASK]
+    assert not torch.equal(after, before)
+    assert torch.equal(after, want)
+    # eager training step after replays: packed operands must be those of the current weights
+    task.train()
+    fresh.train()
+    l1, _, _ = task.step(batch, training=True)
+    l2, _, _ = fresh.step(batch, training=True)
+    assert torch.equal(l1, l2)

@@ -179,3 +179,66 @@ def test_fused_decoder_prologue_and_bn_statistics_equal_the_unfused_path(cuda, m
     assert abs(fused_loss.item() - plain_loss.item()) <= 1e-5 * abs(plain_loss.item())
     # same budget as the oracle comparison above: the summation order of the batch statistics differs
     assert ((fused_grad - plain_grad).norm() / plain_grad.norm()).item() <= 1e-2
+
+
+def test_bf16_graph_training_learns_a_synthetic_segmentation_task(cuda):
+    """end-to-end sanity of the whole bf16 step (forward, loss, every backward kernel, AdamW, hipGraph replay): labels
+    are a deterministic function of the imagery (which of four channels is largest in a 9x9 neighbourhood, plus a
+    brightness class), so the network can learn them -- the loss must fall well below its start and the pixel
+    accuracy rise well above chance within 200 steps"""
+    from flairhip.graph import GraphedTrainStep
+    task, _, _ = make_pair(precision="bf16")
+    g = torch.Generator().manual_seed(17)
+    B, S = 8, 128
+    base = torch.randn(4, B, 5, S // 8, S // 8, generator=g)
+    xs = [F.interpolate(b, size=(S, S), mode="bilinear", align_corners=False) + 0.3 * torch.randn(B, 5, S, S, generator=g)
+          for b in base]
+
+    def label(x):
+        sm = F.avg_pool2d(x[:, :4], 9, stride=1, padding=4)
+        return (sm.argmax(1) + 4 * (x[:, 4:5].mean(1) > 0).long()).to(torch.uint8)  # 8 of the 19 classes occur
+
+    batches = [{MOD: x.to(cuda), TASK: label(x).to(cuda)} for x in xs]
+    task.train()
+    opt = torch.optim.AdamW(task.model.parameters(), lr=2e-2, fused=True)
+    for b in batches[:2]:  # two eager steps size the workspaces, as HipTrainer does before capturing
+        loss, _, _ = task.step(b, training=True)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    first = loss.item()
+    loss = None
+    graphed = GraphedTrainStep(task, opt, batches[0], warmup_steps=0)
+    losses = [graphed(batches[i % 4]).item() for i in range(200)]
+    assert all(l == l for l in losses)
+    task.eval()
+    with torch.no_grad():
+        _, preds, targets = task.step(batches[0])
+    acc = (preds[TASK] == targets[TASK]).float().mean().item()
+    assert min(losses[-8:]) < 0.55 * first, (first, losses[-8:])
+    assert acc > 0.4, acc  # chance is 1/8; eval mode: running statistics + folded operands of the TRAINED weights
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["foreach", "fused"])
+def test_forward_after_an_optimizer_step_uses_the_updated_weights(cuda, fused):
+    """torch's fused AdamW updates parameters without moving their ``_version``; the packed MFMA operands must follow
+    the optimizer regardless (flairhip.nn state epoch): the loss after a step equals the loss of a fresh model that
+    loaded the updated state dict"""
+    task, _, _ = make_pair(precision="bf16")
+    x, t = _inputs(2, 64, 64, seed=11)
+    batch = {MOD: x.to(cuda), TASK: t.to(cuda)}
+    task.train()
+    opt = torch.optim.AdamW(task.model.parameters(), lr=5e-2, fused=fused)
+    for _ in range(2):
+        loss, _, _ = task.step(batch, training=True)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    first = loss.item()
+    after, _, _ = task.step(batch, training=True)
+    fresh, _, _ = make_pair(precision="bf16", seed=77)
+    fresh.model.load_state_dict(task.model.state_dict())
+    fresh.train()
+    want, _, _ = fresh.step(batch, training=True)
+    assert torch.equal(after.detach(), want.detach())
+    assert abs(after.item() - first) > 1e-3  # lr 0.05: the step visibly moved the loss
