@@ -1468,12 +1468,16 @@ extern "C" int ffa_pack_conv_weight(int dtype, const float* w_oihw, const float*
 // The descriptor table lives in device memory and is built once (ffa_pack_desc_fill on the host, then copied);
 // blockIdx.y selects the descriptor, blockIdx.x strides over its elements.
 
-__device__ __forceinline__ void pack_one(const PackArgs& p, long long i, int dtype) {
+// one thread = eight consecutive channels of one (row, tap): the index arithmetic (seven divisions by run-time
+// values) is paid once per 16-byte store instead of once per element (201 -> ~50 us for the 186 operands of the
+// U-Net at batch time)
+__device__ __forceinline__ void pack_eight(const PackArgs& p, long long i8, int dtype) {
   const int EPC = (dtype == FFA_BF16) ? 16 : 8;
+  const int G8 = EPC / 8;
   const int taps = p.rg * p.kw;
   const int nrg = p.kh / p.rg;
-  long long t = i;
-  const int e = t % EPC; t /= EPC;
+  long long t = i8;
+  const int e0 = (int)(t % G8) * 8; t /= G8;
   const int tap = t % taps; t /= taps;
   const int row_l = t % p.bco; t /= p.bco;
   const int rg = t % nrg; t /= nrg;
@@ -1485,31 +1489,35 @@ __device__ __forceinline__ void pack_one(const PackArgs& p, long long i, int dty
     row_in_block = (row_l & ~63) + 16 * (rho >> 3) + 8 * ((rho >> 2) & 1) + 4 * mt + (rho & 3);
   }
   const int row = cb * p.bco + row_in_block;
-  const int ch = cc * EPC + e;
+  const int ch0 = cc * EPC + e0;
   int r = rg * p.rg + tap / p.kw;
   int sx = tap % p.kw;
-  float v = 0.f;
-  if (row < p.rows && ch < p.chs) {
-    if (p.flip) {
-      r = p.kh - 1 - r;
-      sx = p.kw - 1 - sx;
-    }
-    v = p.src[row * p.s_row + ch * p.s_ch + r * p.kw + sx];
-    if (p.scale) v *= p.scale[row];
+  if (p.flip) {
+    r = p.kh - 1 - r;
+    sx = p.kw - 1 - sx;
+  }
+  float v[8];
+  const bool row_ok = row < p.rows;
+  const float sc = (row_ok && p.scale) ? p.scale[row] : 1.f;
+  const float* src = p.src + (long long)row * p.s_row + r * p.kw + sx;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = ch0 + j;
+    v[j] = (row_ok && ch < p.chs) ? src[(long long)ch * p.s_ch] * sc : 0.f;
   }
   if (dtype == FFA_BF16)
-    ffa_store_elem<ffa_bf16>(static_cast<ffa_bf16*>(p.dst) + i, v);
+    ffa_store8<ffa_bf16>(static_cast<ffa_bf16*>(p.dst) + i8 * 8, v);
   else
-    ffa_store_elem<float>(static_cast<float*>(p.dst) + i, v);
+    ffa_store8<float>(static_cast<float*>(p.dst) + i8 * 8, v);
 }
 
 __global__ void pack_weight_batched_kernel(const PackArgs* __restrict__ descs, int dtype) {
   const PackArgs p = descs[blockIdx.y];
   const int EPC = (dtype == FFA_BF16) ? 16 : 8;
-  const long long total = (long long)p.ncb * p.nchunks * (p.kh / p.rg) * p.bco * (p.rg * p.kw) * EPC;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+  const long long total8 = (long long)p.ncb * p.nchunks * (p.kh / p.rg) * p.bco * (p.rg * p.kw) * (EPC / 8);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total8;
        i += (long long)gridDim.x * blockDim.x)
-    pack_one(p, i, dtype);
+    pack_eight(p, i, dtype);
 }
 
 extern "C" int ffa_pack_desc_bytes(void) { return (int)sizeof(PackArgs); }

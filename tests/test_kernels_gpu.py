@@ -682,3 +682,28 @@ def test_wgrad_reduce_with_contiguous_output_runs_is_bit_identical(cuda, dtype, 
     got_acc = ops.conv_wgrad(xd, dyd, cout, cin, 3, 3, stride, 1, out=base.clone(), accumulate=True)
     torch.cuda.synchronize()
     assert torch.equal(got, ref) and torch.equal(got_acc, ref_acc)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_batched_weight_pack_equals_the_per_layer_pack(cuda, dtype):
+    """ffa_pack_conv_weights_batched (one launch per optimizer step for every operand of the network) writes the same
+    bytes as ffa_pack_conv_weight layer by layer: forward and transposed (dgrad) operands, 64- and 32-row blocks,
+    3x3 / 1x1 / 7x7, channel counts that need padding"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(31)
+    shapes = [(64, 64, 3, 1), (128, 64, 3, 2), (19, 16, 3, 1), (16, 32, 3, 1), (64, 5, 7, 2), (128, 64, 1, 2),
+              (96, 200, 1, 1), (256, 768, 3, 1)]
+    entries, refs = [], []
+    for O, I, k, stride in shapes:
+        w = torch.randn(O, I, k, k, generator=g).to(cuda)
+        for transpose in ((False, True) if k == 3 and (O, I) != (64, 5) else (False,)):
+            pitch = ops.pad_channels(O if transpose else I)
+            ref = ops.pack_conv_weight(w, dtype, stride, pitch, transpose=transpose)
+            dst = ops.pack_conv_weight(torch.zeros_like(w), dtype, stride, pitch, transpose=transpose)
+            assert not torch.equal(dst.data, ref.data)
+            entries.append((w, dst, transpose))
+            refs.append(ref)
+    ops.PackBatch(entries, dtype).run()
+    torch.cuda.synchronize()
+    for (w, dst, tr), ref in zip(entries, refs):
+        assert torch.equal(dst.data, ref.data), (tuple(w.shape), tr)
