@@ -147,6 +147,9 @@ class HipBatchNorm2d(nn.Module):
 
     def note_batch(self) -> None:
         self._pending_batches += 1  # folded into the device counter lazily (no per-step launch)
+        # the running statistics were just rewritten through raw pointers (no tensor version moved): eval-mode folds
+        # of THIS layer computed earlier are stale even if no optimizer step follows (statistics recalibration passes)
+        self._stats_epoch = getattr(self, "_stats_epoch", 0) + 1
 
     @staticmethod
     def _flush_hook(module, state_dict, prefix, local_metadata):
@@ -556,7 +559,7 @@ def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, relu: bool = True, resid
 def _eval_folded(conv: HipConv2d, bn: HipBatchNorm2d, dtype: torch.dtype):
     """(packed weights with the eval-mode BatchNorm scale folded in, shift vector), cached per parameter version"""
     ver = (conv.weight._version, conv.weight.data_ptr(), bn.weight._version, bn.bias._version,
-           bn.running_mean._version, bn.running_var._version, dtype, _STATE_EPOCH)
+           bn.running_mean._version, bn.running_var._version, dtype, _STATE_EPOCH, getattr(bn, "_stats_epoch", 0))
     hit = conv._cache.get("eval_fold")
     if hit is None or hit[0] != ver:
         scale, shift = ops.bn_eval_params(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,

@@ -242,3 +242,27 @@ def test_forward_after_an_optimizer_step_uses_the_updated_weights(cuda, fused):
     want, _, _ = fresh.step(batch, training=True)
     assert torch.equal(after.detach(), want.detach())
     assert abs(after.item() - first) > 1e-3  # lr 0.05: the step visibly moved the loss
+
+
+def test_eval_follows_running_statistics_updated_without_an_optimizer_step(cuda):
+    """train-mode forwards under no_grad move the BatchNorm running statistics (through raw device pointers, no
+    tensor version changes); the next eval forward must fold the NEW statistics"""
+    task, _, _ = make_pair(precision="bf16")
+    x, t = _inputs(4, 64, 64, seed=13)
+    batch = {MOD: x.to(cuda) * 3.0 + 1.0, TASK: t.to(cuda)}
+    task.eval()
+    with torch.no_grad():
+        before = task.model(batch)[0][TASK].clone()
+    task.train()
+    with torch.no_grad():
+        for _ in range(3):
+            task.model(batch)
+    task.eval()
+    with torch.no_grad():
+        after = task.model(batch)[0][TASK].clone()
+    fresh, _, _ = make_pair(precision="bf16", seed=5)
+    fresh.model.load_state_dict(task.model.state_dict())
+    fresh.eval()
+    with torch.no_grad():
+        want = fresh.model(batch)[0][TASK]
+    assert not torch.equal(after, before) and torch.equal(after, want)
