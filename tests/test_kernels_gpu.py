@@ -707,3 +707,38 @@ def test_batched_weight_pack_equals_the_per_layer_pack(cuda, dtype):
     torch.cuda.synchronize()
     for (w, dst, tr), ref in zip(entries, refs):
         assert torch.equal(dst.data, ref.data), (tuple(w.shape), tr)
+
+
+def test_confusion_matrix_kernel_and_jaccard_index(cuda):
+    """the metric update inside the training step (LDS histogram kernel, no host sync) against numpy: exact counts
+    over several updates; macro / per-class / weighted Jaccard with the torchmetrics conventions the reference's
+    SegmentationTask relies on (tasks_module.py:63-93): classes absent from predictions AND targets are left out of
+    the macro mean, average=None reports NaN for them"""
+    from flair_hub.tasks.metrics import MulticlassJaccardIndex
+    g = np.random.default_rng(4)
+    K = 19
+    m = MulticlassJaccardIndex(K, average="macro").to(cuda)
+    cm = np.zeros((K, K), np.int64)
+    for shape in ((2, 64, 96), (3, 40, 40), (1, 512, 512)):
+        t = g.integers(0, 15, shape).astype(np.uint8)  # classes 15..18 never occur
+        p = np.where(g.random(shape) < 0.7, t, g.integers(0, 17, shape)).astype(np.uint8)
+        m.update(torch.from_numpy(p).to(cuda), torch.from_numpy(t).to(cuda))
+        np.add.at(cm, (t.reshape(-1), p.reshape(-1)), 1)
+    assert np.array_equal(m.confmat.cpu().numpy(), cm)
+    tp = np.diag(cm).astype(np.float64)
+    union = cm.sum(0) + cm.sum(1) - tp
+    iou = tp[union > 0] / union[union > 0]
+    assert abs(m.compute().item() - iou.mean()) < 1e-6
+    assert (union == 0).sum() == 2  # 17 and 18: neither predicted nor present
+    per_class = MulticlassJaccardIndex(K, average=None).to(cuda)
+    per_class.confmat.copy_(m.confmat)
+    pc = per_class.compute().cpu().numpy()
+    assert np.isnan(pc[17]) and np.isnan(pc[18]) and np.allclose(pc[union > 0], iou, atol=1e-6)
+    # the torch fallback (CPU tensors / other dtypes) counts the same
+    m2 = MulticlassJaccardIndex(K)
+    m2.update(torch.from_numpy(p.astype(np.int64)), torch.from_numpy(t.astype(np.int64)))
+    ref = np.zeros((K, K), np.int64)
+    np.add.at(ref, (t.reshape(-1), p.reshape(-1)), 1)
+    assert np.array_equal(m2.confmat.numpy(), ref)
+    m.reset()
+    assert int(m.confmat.sum()) == 0
