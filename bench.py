@@ -38,6 +38,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3
 TASK = "AERIAL_LABEL-COSIA"
 MOD = "AERIAL_RGBI"
+SETTLE_MAX_STEPS = 200  # untimed steps the settle phase may take before the counted warm-up
 
 
 def _hk_tag(w, dtype) -> str:
@@ -266,7 +267,7 @@ def main():
 
     total_steps = args.steps + args.warmup
     cfg = unet_resnet34_config(in_channels=5, precision=args.precision, batch_size=args.batch,
-                               total_steps=total_steps + 16)  # + graph warm-up and roofline-pass steps
+                               total_steps=total_steps + 16 + SETTLE_MAX_STEPS)  # + graph warm-up, settle, roofline pass
     torch.manual_seed(cfg["hyperparams"]["seed"])
     task = build_segmentation_module(cfg, {MOD: args.tile}, "train").to(dev)
     task.train()
@@ -315,13 +316,29 @@ def main():
                 sync = GradSync(task.model, broadcast_from_rank0=False)
     step = (lambda i: graphed(batch)) if use_graph else eager_step
 
-    if not use_graph:
-        # eager steps allocate (activations, gradients): let the caching allocator reach its steady state before the
-        # counted warm-up -- on some boxes the first ~15 eager steps ran at 23-25 ms (device-synchronising hipMalloc
-        # calls) against 15.5 afterwards; a graph replay owns its memory from the capture on and does not need this
-        for i in range(8):
-            eager_step(i)
+    # Settle phase, before the counted warm-up: a fresh box starts with the GPU in a low power state and (eager mode)
+    # an allocator that still grows -- the first 10-25 steps were measured at 23-25 ms against 15.5 afterwards on
+    # some boxes.  Run windows of ten steps until two consecutive windows agree within 1.5 % (at most
+    # SETTLE_MAX_STEPS steps / 3 s); every rank runs the same number of windows.
+    prev, calm, t_settle = None, 0, time.perf_counter()
+    for w in range(SETTLE_MAX_STEPS // 10):
         torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(10):
+            step(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        calm = calm + 1 if (prev is not None and abs(dt - prev) <= 0.015 * prev) else 0
+        prev = dt
+        stop = calm >= 2 or time.perf_counter() - t_settle > 3.0
+        if world > 1:  # a common decision (the collectives inside the step need every rank)
+            flag = torch.tensor([1.0 if stop else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            stop = bool(flag.item() > 0.5)
+        if stop:
+            break
+    if rank == 0:
+        print(f"[bench] settle: {10 * (w + 1)} steps, last window {prev / 10 * 1e3:.2f} ms/step", file=sys.stderr)
     for i in range(args.warmup):
         step(i)
     if world > 1:
