@@ -322,3 +322,47 @@ def test_tile_batcher_equals_dataset_plus_default_collate():
     plain = MultiModalSlicedDataset(df, mods, {MOD: P}, "05-15", {"labels": [], "labels_configs": {}})
     ref = (want[0][MOD][1].double() - torch.tensor(mean).double()[:, None, None]) / torch.tensor(std).double()[:, None, None]
     assert torch.allclose(plain[1][MOD].double(), ref, atol=1e-6)  # host normalisation path unchanged
+
+
+def test_configure_optimizers_variants_mirror_the_reference():
+    """tasks_module.py:344-391: AdamW / Adam / SGD and the three scheduler modes, with the reference's constants
+    (OneCycleLR div_factor 1000 without momentum cycling, plateau factor 0.5 / cooldown 4 / min_lr 1e-7,
+    cycle_then_plateau = warm-up cycle of int(fraction * total) steps followed by the plateau scheduler)"""
+    import torch
+    from flairhip.configs import unet_resnet34_config
+    from flair_hub.tasks.module_setup import build_segmentation_module
+    sched = torch.optim.lr_scheduler
+
+    def task_for(**hyper):
+        cfg = unet_resnet34_config(in_channels=5, precision="bf16", total_steps=100)
+        cfg["hyperparams"].update(hyper)
+        return build_segmentation_module(cfg, {"AERIAL_RGBI": 512}, "train"), cfg
+
+    task, cfg = task_for()  # defaults: adamw + one_cycle_lr
+    out = task.configure_optimizers()
+    opt, sc = out["optimizer"], out["lr_scheduler"]
+    assert isinstance(opt, torch.optim.AdamW) and sc["interval"] == "step" and isinstance(sc["scheduler"], sched.OneCycleLR)
+    g = opt.param_groups[0]
+    assert g["weight_decay"] == 0.01 and tuple(g["betas"]) == (0.9, 0.999) and not g.get("fused")  # CPU parameters
+    assert abs(g["lr"] - 5e-5 / 1000) < 1e-12 and sc["scheduler"].total_steps == 100  # starts at max_lr / div_factor
+    assert len(g["params"]) == len(list(task.model.parameters()))
+
+    task, _ = task_for(optimizer="sgd", scheduler="reduce_on_plateau", plateau_patience=7)
+    out = task.configure_optimizers()
+    assert isinstance(out["optimizer"], torch.optim.SGD) and out["optimizer"].param_groups[0]["lr"] == 5e-5
+    rs = out["lr_scheduler"]
+    assert rs["monitor"] == "val_loss" and rs["interval"] == "epoch" and isinstance(rs["scheduler"], sched.ReduceLROnPlateau)
+    assert (rs["scheduler"].factor, rs["scheduler"].patience, rs["scheduler"].cooldown) == (0.5, 7, 4)
+    assert rs["scheduler"].min_lrs == [1e-7]
+
+    task, _ = task_for(optimizer="adam", scheduler="cycle_then_plateau", warmup_fraction=0.2)
+    out = task.configure_optimizers()
+    assert isinstance(out["optimizer"], torch.optim.Adam) and not isinstance(out["optimizer"], torch.optim.AdamW)
+    assert set(out) == {"optimizer"} and task._warmup_scheduler.total_steps == 20
+    assert isinstance(task._plateau_scheduler, sched.ReduceLROnPlateau) and task._plateau_scheduler.patience == 10
+
+    task, _ = task_for(scheduler=None)
+    assert isinstance(task.configure_optimizers(), torch.optim.AdamW)  # bare optimizer, as the reference returns it
+    task, _ = task_for(optimizer="lamb")
+    with pytest.raises(ValueError):
+        task.configure_optimizers()
