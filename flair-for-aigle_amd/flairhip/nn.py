@@ -401,6 +401,19 @@ class _ConvBias(torch.autograd.Function):
         return dx, dw, db, None
 
 
+def _fusion_slice(conv: HipConv2d, w: torch.Tensor, off: int, c: int, dtype: torch.dtype, pitch: int,
+                  transpose: bool) -> ops.PackedWeight:
+    """MFMA operand of the column block W[:, off:off+c] of a fusion 1x1 weight, cached until the weight changes
+    (an inference loop packs each block once instead of once per batch)"""
+    key = ("fusion_slice", off, c, dtype, pitch, transpose)
+    ver = (conv.weight._version, conv.weight.data_ptr(), _STATE_EPOCH)
+    hit = conv._cache.get(key)
+    if hit is None or hit[0] != ver:
+        hit = (ver, ops.pack_conv_weight(w[:, off:off + c].contiguous(), dtype, 1, pitch, transpose=transpose))
+        conv._cache[key] = hit
+    return hit[1]
+
+
 class _FusionConv1x1(torch.autograd.Function):
     """y = bias + sum_m W[:, slice_m] x_m -- the 1x1 convolution over the channel concat of several sources
     (FusionHandler.conv_f, flair_hub/models/flair_model.py:470-475,533-541) evaluated WITHOUT the concat: one
@@ -417,7 +430,7 @@ class _FusionConv1x1(torch.autograd.Function):
         w = weight.detach()
         y, off = None, 0
         for m, (x, c) in enumerate(zip(xs, splits)):
-            pw = ops.pack_conv_weight(w[:, off:off + c].contiguous(), x.dtype, 1, x.shape[-1])
+            pw = _fusion_slice(conv, w, off, c, x.dtype, x.shape[-1], False)
             y = ops.conv2d(x, pw, 0, out_pitch, bias=bpad if m == 0 else None, residual=y)
             off += c
         ctx.conv, ctx.splits, ctx.has_bias, ctx.out_pitch = conv, tuple(splits), bias is not None, out_pitch
@@ -433,7 +446,7 @@ class _FusionConv1x1(torch.autograd.Function):
         for m, (x, c) in enumerate(zip(xs, ctx.splits)):
             dx = None
             if ctx.needs_input_grad[4 + m]:
-                pwt = ops.pack_conv_weight(w[:, off:off + c].contiguous(), x.dtype, 1, ctx.out_pitch, transpose=True)
+                pwt = _fusion_slice(conv, w, off, c, x.dtype, ctx.out_pitch, True)
                 dx = ops.conv2d(dy, pwt, 0, x.shape[-1], out_hw=(x.shape[1], x.shape[2]))
             dxs.append(dx)
             if ctx.needs_input_grad[0]:
