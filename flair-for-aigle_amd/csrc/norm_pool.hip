@@ -623,6 +623,235 @@ extern "C" int ffa_bn_bwd(int dtype, const void* x, const void* dy, const void* 
   return ffa_check_launch("bn_bwd");
 }
 
+// ------------------------------------------------------------------------------------------------
+// BatchNorm backward as ONE co-resident kernel for tensors whose dy and x fit the register files of the chip
+// (bf16, <= ~48 MB per tensor): every thread keeps its share of x and of the masked dy in registers across two
+// grid-wide barriers -- pass 1 reads dy, x (and y for the mask-from-output mode) once and leaves per-block partial
+// sums, the blocks then add the partials (one output value per block, fixed order), pass 2 turns the registers into dx.
+// Three passes over memory instead of five and one launch instead of three (reduce, finalize, apply).
+// MEASURED SLOWER and therefore not used by default (flairhip/ops.py FUSED_BN_BWD_COOP): a grid barrier across the
+// eight XCDs costs ~20-25 us (device-scope atomics + L2 write-back / invalidate), so a call takes 72-76 us whatever
+// the tensor size, against 24-55 us for the three kernels on the tensors that fit.
+//
+// The barriers are bounded spins on device-scope counters (zero on entry; the last block to leave zeroes them
+// again): the grid is one 512-thread block per CU, which is co-resident whenever the launch gets the whole chip; if
+// some CUs are busy with another stream's kernels the late blocks simply arrive late.  A barrier that is not
+// satisfied within ~2 s gives up (sets sync[3], which the host wrapper of the NEXT call reports) instead of hanging
+// the device.
+
+#define FFA_COOP_THREADS 512
+
+__device__ __forceinline__ bool ffa_grid_barrier(unsigned* counter, unsigned nblocks, unsigned* fail) {
+  __shared__ int ok_s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(counter, 1u);
+    int ok = 1;
+    unsigned spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < nblocks) {
+      __builtin_amdgcn_s_sleep(16);
+      if (++spins > (1u << 22)) {
+        ok = 0;
+        atomicExch(fail, 1u);
+        break;
+      }
+    }
+    __threadfence();
+    ok_s = ok;
+  }
+  __syncthreads();
+  return ok_s != 0;
+}
+
+__device__ __forceinline__ void ffa_unpack8_bf16(const ffa_u32x4& u, float (&v)[8]) {
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+  v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+  v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+
+template <int ITEMS>
+__global__ void __launch_bounds__(FFA_COOP_THREADS, 1)
+bn_bwd_coop_kernel(const ffa_bf16* __restrict__ x, const ffa_bf16* __restrict__ dy, const ffa_bf16* __restrict__ y,
+                   const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                   const float* __restrict__ rstd, ffa_bf16* __restrict__ dx, ffa_bf16* __restrict__ dres,
+                   float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ws,
+                   unsigned* __restrict__ sync, long long nvec, int C, int relu, float inv_count) {
+  __shared__ float red[FFA_COOP_THREADS][17];
+  __shared__ double dred[FFA_COOP_THREADS / 64];
+  const int CG = C / 8;
+  const int t = threadIdx.x;
+  const long long nthreads = (long long)gridDim.x * FFA_COOP_THREADS;  // a multiple of CG (host-checked)
+  const long long tid_g = (long long)blockIdx.x * FFA_COOP_THREADS + t;
+  const int cg = (int)(tid_g % CG), c0 = cg * 8;
+  float mu[8], rs[8], sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mu[e] = mean[c0 + e];
+    rs[e] = rstd[c0 + e];
+    sc[e] = (gamma ? gamma[c0 + e] : 1.f) * rs[e];       // same expressions as BnBwdOp::init
+    sh[e] = (beta ? beta[c0 + e] : 0.f) - mu[e] * sc[e];
+  }
+  // ---- pass 1: registers <- x, masked dy; per-thread sums in item order ----
+  ffa_u32x4 xr[ITEMS], gr[ITEMS];
+  float a[8], b[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = b[e] = 0.f;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const long long i = tid_g + (long long)k * nthreads;
+    xr[k] = ffa_u32x4{0u, 0u, 0u, 0u};
+    gr[k] = ffa_u32x4{0u, 0u, 0u, 0u};
+    if (i < nvec) {
+      xr[k] = *reinterpret_cast<const ffa_u32x4*>(x + i * 8);
+      ffa_u32x4 g = *reinterpret_cast<const ffa_u32x4*>(dy + i * 8);
+      float xv[8], gv[8];
+      ffa_unpack8_bf16(xr[k], xv);
+      unsigned keep = 0xffu;  // bit e: element e passes the ReLU
+      if (relu == 1) {
+        float yv[8];
+        ffa_unpack8_bf16(*reinterpret_cast<const ffa_u32x4*>(y + i * 8), yv);
+        keep = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) keep |= (yv[e] > 0.f ? 1u : 0u) << e;
+      } else if (relu == 2) {
+        keep = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) keep |= ((xv[e] * sc[e] + sh[e]) > 0.f ? 1u : 0u) << e;
+      }
+      uint32_t w[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        w[q] &= ((keep >> (2 * q)) & 1u ? 0x0000ffffu : 0u) | ((keep >> (2 * q + 1)) & 1u ? 0xffff0000u : 0u);
+      gr[k] = ffa_u32x4{w[0], w[1], w[2], w[3]};
+      ffa_unpack8_bf16(gr[k], gv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        a[e] += gv[e];
+        b[e] += gv[e] * (xv[e] - mu[e]) * rs[e];
+      }
+    }
+  }
+  // block partials: threads of one channel group are t, t + CG, ... (512 % CG == 0)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[t][e] = a[e];
+    red[t][8 + e] = b[e];
+  }
+  __syncthreads();
+  const int PL = FFA_COOP_THREADS / CG;
+  for (int idx = t; idx < 2 * C; idx += FFA_COOP_THREADS) {
+    const int which = idx / C, c = idx % C;
+    const int g = c / 8, e = (c % 8) + which * 8;
+    float s = 0.f;
+    for (int q = 0; q < PL; ++q) s += red[q * CG + g][e];
+    ws[((long long)blockIdx.x * 2 + which) * C + c] = s;
+  }
+  const unsigned nb = gridDim.x;
+  bool ok = ffa_grid_barrier(sync + 0, nb, sync + 3);
+  // ---- totals: value v = which * C + c is summed by block v % nb over the nb block partials, in block order ----
+  float* tot = ws + (long long)FFA_MAX_PARTIALS * 2 * C;  // [2][C]
+  for (int v = blockIdx.x; v < 2 * C; v += nb) {
+    double s = 0.0;
+    for (unsigned p = t; p < nb; p += FFA_COOP_THREADS) s += (double)ws[(long long)p * 2 * C + v];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((t & 63) == 0) dred[t >> 6] = s;
+    __syncthreads();
+    if (t == 0) {
+      double r = 0.0;
+      for (int wv = 0; wv < FFA_COOP_THREADS / 64; ++wv) r += dred[wv];
+      tot[v] = (float)r;
+    }
+    __syncthreads();
+  }
+  ok = ffa_grid_barrier(sync + 1, nb, sync + 3) && ok;
+  // ---- pass 2: dx from the registers ----
+  float kg[8], kx[8], k0[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float s = __hip_atomic_load(tot + c0 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float q = __hip_atomic_load(tot + C + c0 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    kg[e] = (gamma ? gamma[c0 + e] : 1.f) * rs[e];  // same expressions as bn_bwd_finalize_kernel
+    kx[e] = -kg[e] * rs[e] * q * inv_count;
+    k0[e] = -kg[e] * s * inv_count - kx[e] * mu[e];
+    if (blockIdx.x == 0 && t < CG) {  // thread t of block 0 owns channel group t
+      dbeta[c0 + e] = s;
+      dgamma[c0 + e] = q;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const long long i = tid_g + (long long)k * nthreads;
+    if (i < nvec) {
+      float xv[8], gv[8], o[8];
+      ffa_unpack8_bf16(xr[k], xv);
+      ffa_unpack8_bf16(gr[k], gv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = kg[e] * gv[e] + kx[e] * xv[e] + k0[e];
+      ffa_store8<ffa_bf16>(dx + i * 8, o);
+      if (dres) *reinterpret_cast<ffa_u32x4*>(dres + i * 8) = gr[k];
+    }
+  }
+  // ---- leave: the last block out re-arms the counters for the next launch ----
+  __syncthreads();
+  if (t == 0) {
+    __threadfence();
+    if (atomicAdd(sync + 2, 1u) == nb - 1) {
+      sync[0] = 0u;
+      sync[1] = 0u;
+      sync[2] = 0u;
+      __threadfence();
+    }
+  }
+  (void)ok;
+}
+
+// One-kernel form of ffa_bn_bwd (bf16 only).  sync: four uint32 in device memory, zero before the first call and
+// never touched by the caller afterwards (the kernel re-arms them; sync[3] latches a barrier time-out).  Returns
+// FFA_ERR_UNSUPPORTED when the tensor does not fit the register budget of the chip (the caller then uses ffa_bn_bwd).
+extern "C" int ffa_bn_bwd_fused(int dtype, const void* x, const void* dy, const void* y, const float* gamma,
+                                const float* beta, const float* mean, const float* rstd, void* dx, void* dres,
+                                float* dgamma, float* dbeta, long long npix, int C, int relu, void* workspace,
+                                long long workspace_bytes, unsigned* sync, hipStream_t stream) {
+  FFA_REQUIRE(x && dy && dx && mean && rstd && dgamma && dbeta && workspace && sync, "bn_bwd_fused: null pointer");
+  FFA_REQUIRE(relu >= 0 && relu <= 2 && (relu != 1 || y), "bn_bwd_fused: bad relu mode");
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return FFA_ERR_UNSUPPORTED;
+    cus = prop.multiProcessorCount;
+  }
+  const int CG = C / 8;
+  if (dtype != FFA_BF16 || C % 8 != 0 || CG < 1 || FFA_COOP_THREADS % CG != 0 || cus < 8 || cus > FFA_MAX_PARTIALS) {
+    ffa_set_error("bn_bwd_fused: unsupported dtype / channel count %d", C);
+    return FFA_ERR_UNSUPPORTED;
+  }
+  if (workspace_bytes < ffa_bn_workspace_bytes(C)) {
+    ffa_set_error("bn_bwd_fused: workspace too small");
+    return FFA_ERR_WORKSPACE;
+  }
+  const long long nvec = npix * CG;
+  const long long nthreads = (long long)cus * FFA_COOP_THREADS;
+  const long long items = (nvec + nthreads - 1) / nthreads;
+  if (items > 16) {
+    ffa_set_error("bn_bwd_fused: %lld vectors per thread exceed the register budget", items);
+    return FFA_ERR_UNSUPPORTED;
+  }
+  const float inv_count = (float)(1.0 / (double)npix);
+#define FFA_COOP_LAUNCH(N_)                                                                                      \
+  hipLaunchKernelGGL(bn_bwd_coop_kernel<N_>, dim3(cus), dim3(FFA_COOP_THREADS), 0, stream, (const ffa_bf16*)x,   \
+                     (const ffa_bf16*)dy, (const ffa_bf16*)y, gamma, beta, mean, rstd, (ffa_bf16*)dx,            \
+                     (ffa_bf16*)dres, dgamma, dbeta, (float*)workspace, sync, nvec, C, relu, inv_count)
+  // (8 and 24 vectors per thread were tried: hipcc spills both; 16 x 16 B x 2 tensors = 128 data registers fits)
+  if (items <= 4) FFA_COOP_LAUNCH(4);
+  else FFA_COOP_LAUNCH(16);
+#undef FFA_COOP_LAUNCH
+  return ffa_check_launch("bn_bwd_fused");
+}
+
 // ffa_bn_bwd for y = relu(bn_train(x)) when the two reductions were already taken by the producer of dy
 // (ffa_conv2d_bnbwd): partials[nparts][2][C] = per-tile (sum g, sum g*x).  Finalize + apply only.
 extern "C" int ffa_bn_bwd_partials(int dtype, const void* x, const void* dy, const float* partials, long long nparts,

@@ -416,6 +416,31 @@ def bn_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, residual
     return out
 
 
+# one-kernel BatchNorm backward for tensors that fit the chip's registers: OFF by default (FFA_BN_BWD_COOP=1 enables).
+# Measured: a grid-wide barrier across the eight XCDs costs ~20-25 us, two of them more than the two launches and
+# the two passes they save (72-76 us per call whatever the tensor size, against 24-55 us for reduce + finalize +
+# apply on the tensors that fit; 15.49 -> 16.81 ms per training step).  Kept as the measured negative result.
+FUSED_BN_BWD_COOP = os.environ.get("FFA_BN_BWD_COOP", "0") == "1"
+_COOP_SYNC = {}
+
+
+def _coop_sync(device) -> torch.Tensor:
+    """barrier counters of ffa_bn_bwd_fused: zeroed once per device, re-armed by every launch"""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    t = _COOP_SYNC.get(key)
+    if t is None:
+        t = _COOP_SYNC[key] = torch.zeros(4, dtype=torch.int32, device=device)
+    return t
+
+
+def coop_barrier_failed(device=None) -> bool:
+    """True when a grid barrier of ffa_bn_bwd_fused ever timed out on this device (synchronises)"""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    t = _COOP_SYNC.get(key)
+    return bool(t is not None and int(t[3].item()) != 0)
+
+
 def bn_bwd(x: torch.Tensor, dy: torch.Tensor, y: Optional[torch.Tensor], gamma, beta, mean, rstd, relu: bool,
            want_dres: bool):
     """-> (dx, dres or None, dgamma, dbeta).  With relu and y=None the ReLU mask is recomputed from x
@@ -428,6 +453,16 @@ def bn_bwd(x: torch.Tensor, dy: torch.Tensor, y: Optional[torch.Tensor], gamma, 
     dgb = torch.empty((2, C_), dtype=torch.float32, device=dev)
     ws = workspace(lib.ffa_bn_workspace_bytes(C_), dev, "bn")
     mode = 0 if not relu else (1 if y is not None else 2)
+    if FUSED_BN_BWD_COOP and x.dtype == torch.bfloat16:
+        sync = _coop_sync(dev)
+        rc = lib.ffa_bn_bwd_fused(_dt(x), x.data_ptr(), dy.data_ptr(), _ptr(y), _ptr(gamma), _ptr(beta),
+                                  mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _ptr(dres), dgb[0].data_ptr(),
+                                  dgb[1].data_ptr(), x.numel() // C_, C_, mode, ws.data_ptr(), ws.numel(),
+                                  sync.data_ptr(), _stream())
+        if rc == 0:
+            return dx, dres, dgb[0], dgb[1]
+        if rc != _l.ERR_UNSUPPORTED:
+            _l.check(rc, "bn_bwd_fused")
     _l.check(lib.ffa_bn_bwd(_dt(x), x.data_ptr(), dy.data_ptr(), _ptr(y), _ptr(gamma), _ptr(beta), mean.data_ptr(),
                             rstd.data_ptr(), dx.data_ptr(), _ptr(dres), dgb[0].data_ptr(), dgb[1].data_ptr(),
                             x.numel() // C_, C_, mode, ws.data_ptr(), ws.numel(), _stream()), "bn_bwd")

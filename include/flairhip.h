@@ -131,6 +131,14 @@ int ffa_bn_apply(int dtype, const void* x, const void* residual, void* y, const 
 int ffa_bn_bwd(int dtype, const void* x, const void* dy, const void* y, const float* gamma, const float* beta,
                const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, long long npix,
                int C, int relu, void* workspace, long long workspace_bytes, ffa_stream_t stream);
+/* ffa_bn_bwd as ONE co-resident kernel (bf16): x and the masked dy stay in registers across two grid-wide barriers
+ * -- three passes over memory instead of five, one launch instead of three.  sync = four uint32 of device memory,
+ * zero before the first call and owned by the library afterwards (sync[3] != 0: a barrier timed out, results of
+ * that call are invalid).  FFA_ERR_UNSUPPORTED when dy + x do not fit the chip's register files (use ffa_bn_bwd). */
+int ffa_bn_bwd_fused(int dtype, const void* x, const void* dy, const void* y, const float* gamma, const float* beta,
+                     const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta,
+                     long long npix, int C, int relu, void* workspace, long long workspace_bytes, unsigned* sync,
+                     ffa_stream_t stream);
 /* ffa_bn_bwd (ReLU mask recomputed from x) when sum(g) / sum(g*x) per tile already exist (ffa_conv2d_bnbwd) */
 int ffa_bn_bwd_partials(int dtype, const void* x, const void* dy, const float* partials, long long nparts,
                         const float* gamma, const float* beta, const float* mean, const float* rstd, void* dx,

@@ -742,3 +742,49 @@ def test_confusion_matrix_kernel_and_jaccard_index(cuda):
     assert np.array_equal(m2.confmat.numpy(), ref)
     m.reset()
     assert int(m.confmat.sum()) == 0
+
+
+@pytest.mark.parametrize("C,H,W,B,relu,res", [
+    (128, 64, 64, 8, True, False),    # mask recomputed from x; 4 vectors per thread
+    (256, 32, 32, 32, True, True),    # mask from y (residual before the ReLU) + gradient of the residual branch
+    (512, 16, 16, 32, True, False),
+    (128, 64, 64, 32, True, True),    # 16 vectors per thread: the largest tensor that fits (33.5 MB)
+    (64, 24, 40, 3, False, False),    # no ReLU, ragged size (tail threads hold no data)
+])
+def test_one_kernel_bn_backward_matches_the_three_kernel_path(cuda, C, H, W, B, relu, res, monkeypatch):
+    """ffa_bn_bwd_fused (registers held across two grid barriers) against reduce + finalize + apply: dx / dres equal up
+    to one bf16 rounding of values computed from sums that differ in summation order, dgamma / dbeta to 1e-5;
+    repeated calls give identical bits (counters re-arm, fixed order), no barrier time-out"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(C + H)
+    dt = torch.bfloat16
+    x = to_nhwc(torch.randn(B, C, H, W, generator=g), dt, cuda, C)
+    dy = to_nhwc(torch.randn(B, C, H, W, generator=g), dt, cuda, C)
+    resid = to_nhwc(torch.randn(B, C, H, W, generator=g), dt, cuda, C) if res else None
+    gamma = (torch.rand(C, generator=g) + 0.5).to(cuda)
+    beta = torch.randn(C, generator=g).to(cuda)
+    rm, rv = torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
+    scale, shift, mean, rstd = ops.bn_stats(x, gamma, beta, rm, rv, 0.1, 1e-5)
+    y = ops.bn_apply(x, scale, shift, relu=relu, residual=resid) if res else None
+
+    def run():
+        out = ops.bn_bwd(x, dy, y, gamma, beta, mean, rstd, relu, want_dres=res)
+        torch.cuda.synchronize()
+        return out
+
+    monkeypatch.setattr(ops, "FUSED_BN_BWD_COOP", False)
+    ref = run()
+    monkeypatch.setattr(ops, "FUSED_BN_BWD_COOP", True)
+    got = run()
+    again = run()
+    assert not ops.coop_barrier_failed()
+    for a_, b_ in zip(got, again):
+        assert (a_ is None and b_ is None) or torch.equal(a_, b_)
+    dx, dres, dg, db = got
+    rdx, rdres, rdg, rdb = ref
+    assert torch.allclose(dg, rdg, rtol=1e-5, atol=1e-4) and torch.allclose(db, rdb, rtol=1e-5, atol=1e-4)
+    err = (dx.float() - rdx.float()).abs().max().item()
+    assert err <= 2 ** -7 * max(1.0, rdx.float().abs().max().item()), err
+    assert (dx != rdx).float().mean().item() < 0.02  # nearly all elements round the same way
+    if res:
+        assert torch.equal(dres, rdres)  # the masked gradient itself involves no sums
