@@ -1190,6 +1190,32 @@ extern "C" int ffa_conv_block_co(int kh, int kw, int stride, int cout) {
   return conv_supported(kh, kw, stride, bco) ? bco : FFA_ERR_UNSUPPORTED;
 }
 
+// ring kernel entry points (conv3x3_ring.hip)
+extern "C" long long ffa_ring_stat_rows(int B, int H, int W, int co_rows);
+extern "C" int ffa_ring_conv3x3(int dtype, const void* in, const void* w_ring, const float* bias, const void* residual,
+                                void* out, float* stat_partials, const float* pro_scale, const float* pro_shift, int B,
+                                int H, int W, int Ci, int Co, int co_rows, int relu, hipStream_t stream);
+extern "C" int ffa_ring_pack(int dtype, const float* w_oihw, const float* scale, void* dst, int O, int I, int transpose,
+                             int co_rows, int ci_pitch, hipStream_t stream);
+
+// Operand layout + block height for a layer: the value to hand to ffa_pack_conv_weight / ffa_conv2d as `bco`.
+// Bits 0..11 = rows per block (the padded row count is a multiple of it); FFA_BCO_RING set = the operand is packed
+// for conv3x3_ring_kernel (3x3 stride 1 pad 1, >= 64 rows, whole 64-byte groups of input channels; plain
+// ffa_conv2d / ffa_conv2d_stats calls only -- pass allow_ring = 0 for operands used by the two-source, split-epilogue
+// or zero-insertion (dil = 2) calls).  The ring layout is chosen only with FFA_RING=1 in the environment: measured
+// on MI355X it equals conv3x3_persist_kernel on the 128 / 256-channel layers and trails it by 2-6 % on the 64- and
+// 512-channel ones, so the default stays with the conv_igemm operands.
+extern "C" int ffa_conv_plan(int dtype, int kh, int kw, int stride, int cout, int ci_pitch, int allow_ring) {
+  const int bco = ffa_conv_block_co(kh, kw, stride, cout);
+  if (bco < 0) return bco;
+  const char* e = getenv("FFA_RING");
+  const int eb = (dtype == FFA_BF16) ? 2 : 4;
+  if (allow_ring && e && e[0] == '1' && kh == 3 && kw == 3 && stride == 1 && cout >= 64 &&
+      (ci_pitch * eb) % 64 == 0)
+    return 64 | FFA_BCO_RING;
+  return bco;
+}
+
 extern "C" int ffa_conv_row_group(int kh) { return conv_rg(kh); }
 
 static int conv2d_impl(int dtype, const void* in, const void* w_packed, const float* bias, const void* residual,
@@ -1205,6 +1231,13 @@ static int conv2d_impl(int dtype, const void* in, const void* w_packed, const fl
   FFA_REQUIRE(dil == 1 || stride == 1, "conv: zero-insertion input needs stride 1");
   FFA_REQUIRE((long long)B * Hi * Wi * Ci * (dtype == FFA_BF16 ? 2 : 4) < (1LL << 31),
               "conv: input tensor must be smaller than 2 GiB (32-bit piece offsets)");
+  if (bco & FFA_BCO_RING) {
+    FFA_REQUIRE(kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && Hi == Ho && Wi == Wo && c1_out == 0 &&
+                    bnx == nullptr,
+                "conv: a ring-layout operand serves plain 3x3 stride-1 pad-1 convolutions only");
+    return ffa_ring_conv3x3(dtype, in, w_packed, bias, residual, out, stat_partials, nullptr, nullptr, B, Hi, Wi, Ci, Co,
+                            co_rows, relu, stream);
+  }
   if (!conv_supported(kh, kw, stride, bco)) {
     ffa_set_error("conv: unsupported kernel %dx%d stride %d block %d", kh, kw, stride, bco);
     return FFA_ERR_UNSUPPORTED;
@@ -1263,9 +1296,15 @@ extern "C" int ffa_conv2d_bnbwd(int dtype, const void* in, const void* w_packed,
 }
 
 // Number of partial-statistics rows ffa_conv2d_stats writes for an output of B x Ho x Wo pixels (= pixel tiles).
-extern "C" long long ffa_conv_stat_rows(int B, int Ho, int Wo) {
+static long long conv_stat_rows_igemm(int B, int Ho, int Wo) {
   const int tw = (Wo >= 32) ? 32 : 16, th = (Wo >= 32) ? 8 : 16;
   return (long long)B * ffa_cdiv(Wo, tw) * ffa_cdiv(Ho, th);
+}
+// co_rows / bco: the operand the convolution will run with (ffa_conv_plan); the row count is the number of pixel
+// tiles of the kernel that serves it
+extern "C" long long ffa_conv_stat_rows(int B, int Ho, int Wo, int co_rows, int bco) {
+  if (bco & FFA_BCO_RING) return ffa_ring_stat_rows(B, Ho, Wo, co_rows);
+  return conv_stat_rows_igemm(B, Ho, Wo);
 }
 
 // 1 when ffa_conv2d / ffa_conv2d_stats run this convolution on the persistent kernel (conv3x3_persist_kernel: its
@@ -1275,7 +1314,8 @@ extern "C" int ffa_conv_is_persistent(int dtype, int B, int Ho, int Wo, int Ci, 
   if (!(kh == 3 && kw == 3 && stride == 1) || bco <= 0 || co_rows % bco != 0) return 0;
   const int nchunks = Ci * (dtype == FFA_BF16 ? 2 : 4) / 32;
   if (nchunks % 2 != 0) return 0;  // HK = 1 instantiations have no pipelined path
-  const int npt = (int)ffa_conv_stat_rows(B, Ho, Wo);
+  if (bco & FFA_BCO_RING) return 0;
+  const int npt = (int)conv_stat_rows_igemm(B, Ho, Wo);
   return conv_persist_grid(dil, 0, nullptr, ffa_cdiv(npt, 8) * 8 * (co_rows / bco)) > 0 ? 1 : 0;
 }
 
@@ -1431,6 +1471,10 @@ extern "C" int ffa_pack_conv_weight(int dtype, const float* w_oihw, const float*
                                     hipStream_t stream) {
   FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "pack: bad dtype");
   FFA_REQUIRE(w_oihw && dst, "pack: null pointer");
+  if (bco & FFA_BCO_RING) {
+    FFA_REQUIRE(kh == 3 && kw == 3, "pack: the ring layout is for 3x3 kernels");
+    return ffa_ring_pack(dtype, w_oihw, scale, dst, O, I, transpose, co_rows, ci_pitch, stream);
+  }
   FFA_REQUIRE(bco > 0 && co_rows % bco == 0, "pack: rows %d not a multiple of block %d", co_rows, bco);
   FFA_REQUIRE(rg > 0 && kh % rg == 0, "pack: bad row group");
   const int epc = (dtype == FFA_BF16) ? 16 : 8;

@@ -19,6 +19,8 @@
 #define FFA_ERR_UNSUPPORTED (-2)
 #define FFA_ERR_WORKSPACE (-3)
 
+#define FFA_BCO_RING 0x1000  // `bco` flag: operand packed for conv3x3_ring_kernel (ffa_conv_plan)
+
 void ffa_set_error(const char* fmt, ...);
 int ffa_check_launch(const char* what);
 

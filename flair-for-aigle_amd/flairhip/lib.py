@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("FLAIRHIP_LIB") or os.path.join(_HERE, "libflairhip.so
 
 BF16 = 0
 F32 = 1
+BCO_RING = 0x1000  # FFA_BCO_RING
 ERR_UNSUPPORTED = -2  # FFA_ERR_UNSUPPORTED: no kernel for the requested shape (callers may fall back to another op)
 
 
@@ -50,7 +51,14 @@ SIGNATURES = {
     "ffa_pack_desc_fill": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "ffa_pack_conv_weights_batched": (_i, [_i, _p, _i, _p]),
     "ffa_conv2d": (_i, [_i, _p, _p, _p, _p, _p] + [_i] * 15 + [_p]),
-    "ffa_conv_stat_rows": (_ll, [_i, _i, _i]),
+    "ffa_conv_stat_rows": (_ll, [_i, _i, _i, _i, _i]),
+    "ffa_conv_plan": (_i, [_i] * 7),
+    "ffa_ring_conv3x3": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
+    "ffa_ring_stat_rows": (_ll, [_i, _i, _i, _i]),
+    "ffa_ring_pack": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "ffa_ring_pack_desc_bytes": (_i, []),
+    "ffa_ring_pack_desc_fill": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
+    "ffa_ring_pack_batched": (_i, [_i, _p, _i, _p]),
     "ffa_conv2d_stats": (_i, [_i, _p, _p, _p, _p, _p, _p] + [_i] * 15 + [_p]),
     "ffa_conv2d_bnbwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 14 + [_p]),
     "ffa_bn_bwd_partials": (_i, [_i, _p, _p, _p, _ll, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _p, _ll, _p]),

@@ -45,8 +45,12 @@ class HipConv2d(nn.Module):
             self.out_channels)
 
     def packed(self, dtype: torch.dtype, transpose: bool = False, scale: Optional[torch.Tensor] = None,
-               tag: str = "") -> ops.PackedWeight:
-        """MFMA operand for the current weight values; re-packed only when the parameter changed."""
+               tag: str = "", ring: bool = True) -> ops.PackedWeight:
+        """MFMA operand for the current weight values; re-packed only when the parameter changed.  ring=False keeps
+        the conv_igemm layout (operands of the two-source / split-epilogue / bn-backward-epilogue kernels)."""
+        ring = ring and self.padding == 1  # the ring kernel is a pad-1 kernel
+        if not ring and not tag:
+            tag = "igemm"
         key = (dtype, transpose, tag)
         ver = (self.weight._version, self.weight.data_ptr(), None if scale is None else scale._version, _STATE_EPOCH)
         hit = self._cache.get(key)
@@ -56,7 +60,7 @@ class HipConv2d(nn.Module):
         if not w.is_contiguous():
             w = w.contiguous()
         pitch = self.out_pitch if transpose else self.in_pitch
-        pw = ops.pack_conv_weight(w, dtype, self.stride, pitch, transpose=transpose, scale=scale)
+        pw = ops.pack_conv_weight(w, dtype, self.stride, pitch, transpose=transpose, scale=scale, allow_ring=ring)
         self._cache[key] = (ver, pw)
         return pw
 
@@ -108,26 +112,27 @@ class PackPlan:
         entries, sig, slots = [], [], []
         for c in self.convs:
             for transpose in (False, True):
-                hit = c._cache.get((dtype, transpose, ""))
-                if hit is None:
-                    continue
-                entries.append((c.weight.detach(), hit[1], transpose))
-                sig.append((c.weight.data_ptr(), hit[1].data.data_ptr()))
-                slots.append((c, transpose))
+                for tag in ("", "igemm"):
+                    hit = c._cache.get((dtype, transpose, tag))
+                    if hit is None:
+                        continue
+                    entries.append((c.weight.detach(), hit[1], transpose))
+                    sig.append((c.weight.data_ptr(), hit[1].data.data_ptr()))
+                    slots.append((c, transpose, tag))
         if not entries:
             return
-        versions = [c.weight._version for c, _ in slots]
+        versions = [c.weight._version for c, _, _ in slots]
         if self.batch is None or sig != self.sig:
             if not all(e[0].is_contiguous() for e in entries):
                 return
             self.batch, self.sig, self.versions = ops.PackBatch(entries, dtype), sig, None
-        stale = [i for i, (c, tr) in enumerate(slots)
-                 if c._cache[(dtype, tr, "")][0][0] != versions[i] or c._cache[(dtype, tr, "")][0][3] != _STATE_EPOCH]
+        stale = [i for i, (c, tr, tag) in enumerate(slots)
+                 if c._cache[(dtype, tr, tag)][0][0] != versions[i] or c._cache[(dtype, tr, tag)][0][3] != _STATE_EPOCH]
         if not stale:
             return
         self.batch.run()
-        for (c, tr), v in zip(slots, versions):
-            key = (dtype, tr, "")
+        for (c, tr, tag), v in zip(slots, versions):
+            key = (dtype, tr, tag)
             c._cache[key] = ((v, c.weight.data_ptr(), None, _STATE_EPOCH), c._cache[key][1])
 
 
@@ -208,7 +213,7 @@ class _UpConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, lo, skip, weight, gamma, beta, conv: HipConv2d, bn: HipBatchNorm2d):
-        y0, scale, shift, mean, rstd = ops.conv2d_upcat_bn_stats(lo, skip, conv.packed(lo.dtype), conv.out_pitch, gamma,
+        y0, scale, shift, mean, rstd = ops.conv2d_upcat_bn_stats(lo, skip, conv.packed(lo.dtype, ring=False), conv.out_pitch, gamma,
                                                                  beta, bn.running_mean, bn.running_var, bn.momentum,
                                                                  bn.eps)
         bn.note_batch()
@@ -224,7 +229,7 @@ class _UpConvBnAct(torch.autograd.Function):
         d0, _, dgamma, dbeta = ops.bn_bwd(y0, _as_nhwc_grad(dy), None, gamma, beta, mean, rstd, True, False)
         dlo = dskip = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            pwt = conv.packed(d0.dtype, transpose=True)
+            pwt = conv.packed(d0.dtype, transpose=True, ring=False)
             c1, c2 = lo.shape[-1], (0 if skip is None else skip.shape[-1])
             pair = ops.conv2d_dgrad_upcat(d0, pwt, c1, c2)  # dlo pooled in the dgrad epilogue, dskip written directly
             if pair is None:
@@ -248,7 +253,7 @@ class _DecoderBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lo, skip, wa, ga, ba, wb, gb, bb, blk):
         ca, na, cb, nb = blk.conv1[0], blk.conv1[1], blk.conv2[0], blk.conv2[1]
-        xa, sca, sha, ma, ra = ops.conv2d_upcat_bn_stats(lo, skip, ca.packed(lo.dtype), ca.out_pitch, ga, ba,
+        xa, sca, sha, ma, ra = ops.conv2d_upcat_bn_stats(lo, skip, ca.packed(lo.dtype, ring=False), ca.out_pitch, ga, ba,
                                                          na.running_mean, na.running_var, na.momentum, na.eps)
         na.note_batch()
         ya = ops.bn_apply(xa, sca, sha, relu=True)
@@ -267,7 +272,7 @@ class _DecoderBlock(torch.autograd.Function):
         ca, cb = blk.conv1[0], blk.conv2[0]
         db_, _, dgb, dbb = ops.bn_bwd(xb, _as_nhwc_grad(dy), None, gb, bb, mb, rb, True, False)
         dwb = ops.conv_wgrad(ya, db_, cb.out_channels, cb.in_channels, 3, 3, 1, 1) if ctx.needs_input_grad[5] else None
-        pbt = cb.packed(db_.dtype, transpose=True)
+        pbt = cb.packed(db_.dtype, transpose=True, ring=not ops.FUSED_BN_BWD)
         if ops.FUSED_BN_BWD:
             dya, part, rows = ops.conv2d_bnbwd(db_, pbt, 1, ya.shape[-1], xa, sca, sha)
             da, dga, dba = ops.bn_bwd_partials(xa, dya, part, rows, ga, ba, ma, ra)
@@ -276,7 +281,7 @@ class _DecoderBlock(torch.autograd.Function):
             da, _, dga, dba = ops.bn_bwd(xa, dya, None, ga, ba, ma, ra, True, False)
         dlo = dskip = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            pat = ca.packed(da.dtype, transpose=True)
+            pat = ca.packed(da.dtype, transpose=True, ring=False)
             c1, c2 = lo.shape[-1], (0 if skip is None else skip.shape[-1])
             pair = ops.conv2d_dgrad_upcat(da, pat, c1, c2)
             if pair is None:
@@ -347,7 +352,7 @@ class _BasicBlock(torch.autograd.Function):
         dw2 = wgrad(c2, y1, d2) if ctx.needs_input_grad[4] else None
         if ops.FUSED_BN_BWD:
             # bn1's backward reductions come out of conv2's dgrad epilogue (one pass over x1 and dy1 fewer)
-            dy1, part, rows = ops.conv2d_bnbwd(d2, c2.packed(d2.dtype, transpose=True), c2.kernel_size - 1 - c2.padding,
+            dy1, part, rows = ops.conv2d_bnbwd(d2, c2.packed(d2.dtype, transpose=True, ring=False), c2.kernel_size - 1 - c2.padding,
                                                y1.shape[-1], x1, sc1, sh1)
             d1, dg1, db1 = ops.bn_bwd_partials(x1, dy1, part, rows, g1, b1, m1, r1)
         else:
@@ -569,19 +574,20 @@ def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, relu: bool = True, resid
     return ops.conv2d(x, pw, conv.padding, conv.out_pitch, bias=shift, residual=residual, relu=relu)
 
 
-def _eval_folded(conv: HipConv2d, bn: HipBatchNorm2d, dtype: torch.dtype):
+def _eval_folded(conv: HipConv2d, bn: HipBatchNorm2d, dtype: torch.dtype, ring: bool = True):
     """(packed weights with the eval-mode BatchNorm scale folded in, shift vector), cached per parameter version"""
     ver = (conv.weight._version, conv.weight.data_ptr(), bn.weight._version, bn.bias._version,
            bn.running_mean._version, bn.running_var._version, dtype, _STATE_EPOCH, getattr(bn, "_stats_epoch", 0))
-    hit = conv._cache.get("eval_fold")
+    ck = "eval_fold" if ring else "eval_fold_igemm"
+    hit = conv._cache.get(ck)
     if hit is None or hit[0] != ver:
         scale, shift = ops.bn_eval_params(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                           bn.eps)
         w = conv.weight.detach()
         pw = ops.pack_conv_weight(w if w.is_contiguous() else w.contiguous(), dtype, conv.stride, conv.in_pitch,
-                                  scale=scale)
+                                  scale=scale, allow_ring=ring)
         hit = (ver, pw, shift)
-        conv._cache["eval_fold"] = hit
+        conv._cache[ck] = hit
     return hit[1], hit[2]
 
 
@@ -593,7 +599,7 @@ def up_conv_bn_act(lo, skip, conv: HipConv2d, bn: HipBatchNorm2d):
             ops.upcat_supported(c1, c2, lo.dtype):
         if bn.training:
             return _UpConvBnAct.apply(lo, skip, conv.weight, bn.weight, bn.bias, conv, bn)
-        pw, shift = _eval_folded(conv, bn, lo.dtype)
+        pw, shift = _eval_folded(conv, bn, lo.dtype, ring=False)
         y = ops.conv2d_upcat(lo, skip, pw, conv.out_pitch, bias=shift, relu=True)
         if y is not None:
             return y

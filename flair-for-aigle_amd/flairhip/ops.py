@@ -79,20 +79,26 @@ class PackedWeight:
 
 
 def pack_conv_weight(w_oihw: torch.Tensor, dtype: torch.dtype, stride: int, ci_pitch: int,
-                     transpose: bool = False, scale: Optional[torch.Tensor] = None) -> PackedWeight:
-    """OIHW f32 master weight -> MFMA operand for ffa_conv2d (forward, or dgrad when transpose=True)."""
+                     transpose: bool = False, scale: Optional[torch.Tensor] = None,
+                     allow_ring: bool = True) -> PackedWeight:
+    """OIHW f32 master weight -> MFMA operand for ffa_conv2d (forward, or dgrad when transpose=True).
+    allow_ring=False keeps the operand in the conv_igemm layout (needed by the two-source / split-epilogue /
+    zero-insertion calls); otherwise ffa_conv_plan picks the LDS-DMA ring layout where it applies."""
     lib = _l.load()
     if w_oihw.dtype != torch.float32 or not w_oihw.is_contiguous():
         raise ValueError("pack_conv_weight: master weight must be contiguous f32 OIHW")
     O, I, kh, kw = w_oihw.shape
     rows_real = I if transpose else O
     use_stride = 1 if transpose else stride
-    bco = lib.ffa_conv_block_co(kh, kw, use_stride, rows_real)
+    did = _dtype_id(dtype)
+    # the dgrad operand of a stride-2 layer is read through the zero insertion (dil = 2): conv_igemm only
+    ring_ok = allow_ring and not (transpose and stride != 1)
+    bco = lib.ffa_conv_plan(did, kh, kw, use_stride, rows_real, ci_pitch, 1 if ring_ok else 0)
     if bco <= 0:
         raise _l.FlairHipError(f"no conv kernel for {kh}x{kw} stride {use_stride}")
-    rows = (rows_real + bco - 1) // bco * bco
+    blk = bco & 0xFFF
+    rows = (rows_real + blk - 1) // blk * blk
     rg = lib.ffa_conv_row_group(kh)
-    did = _dtype_id(dtype)
     nbytes = lib.ffa_pack_conv_weight_bytes(did, rows, ci_pitch, kh, kw)
     dst = torch.empty(nbytes // (2 if dtype == torch.bfloat16 else 4), dtype=dtype, device=w_oihw.device)
     _l.check(lib.ffa_pack_conv_weight(did, w_oihw.data_ptr(), _ptr(scale), dst.data_ptr(), O, I, kh, kw,
@@ -101,31 +107,52 @@ def pack_conv_weight(w_oihw: torch.Tensor, dtype: torch.dtype, stride: int, ci_p
 
 
 class PackBatch:
-    """Descriptor table for ffa_pack_conv_weights_batched: re-packs many conv operands in one launch.
+    """Descriptor tables for ffa_pack_conv_weights_batched / ffa_ring_pack_batched: re-packs many conv operands in one
+    launch per layout.
 
-    entries: (master weight OIHW f32, PackedWeight it feeds, transpose flag).  The table holds raw device
-    pointers, so it must be rebuilt when a parameter or a packed buffer is re-allocated."""
+    entries: (master weight OIHW f32, PackedWeight it feeds, transpose flag).  The tables hold raw device
+    pointers, so they must be rebuilt when a parameter or a packed buffer is re-allocated."""
 
     def __init__(self, entries, dtype: torch.dtype):
         lib = _l.load()
         self.dtype_id = _dtype_id(dtype)
-        self.n = len(entries)
-        nb = lib.ffa_pack_desc_bytes()
-        host = C.create_string_buffer(nb * self.n)
-        base = C.addressof(host)
         self.keep = []
-        for i, (w, pw, transpose) in enumerate(entries):
-            O, I, kh, kw = w.shape
-            _l.check(lib.ffa_pack_desc_fill(base + i * nb, w.data_ptr(), None, pw.data.data_ptr(), O, I, kh, kw,
-                                            1 if transpose else 0, pw.rows, pw.ci_pitch, pw.bco,
-                                            lib.ffa_conv_row_group(kh), self.dtype_id), "pack_desc_fill")
-            self.keep.append((w, pw))
-        self.table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(entries[0][0].device)
+        plain = [e for e in entries if not (e[1].bco & _l.BCO_RING)]
+        ring = [e for e in entries if e[1].bco & _l.BCO_RING]
+        self.n, self.table = len(plain), None
+        self.n_ring, self.table_ring = len(ring), None
+        dev = entries[0][0].device
+        if plain:
+            nb = lib.ffa_pack_desc_bytes()
+            host = C.create_string_buffer(nb * len(plain))
+            base = C.addressof(host)
+            for i, (w, pw, transpose) in enumerate(plain):
+                O, I, kh, kw = w.shape
+                _l.check(lib.ffa_pack_desc_fill(base + i * nb, w.data_ptr(), None, pw.data.data_ptr(), O, I, kh, kw,
+                                                1 if transpose else 0, pw.rows, pw.ci_pitch, pw.bco,
+                                                lib.ffa_conv_row_group(kh), self.dtype_id), "pack_desc_fill")
+                self.keep.append((w, pw))
+            self.table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
+        if ring:
+            nb = lib.ffa_ring_pack_desc_bytes()
+            host = C.create_string_buffer(nb * len(ring))
+            base = C.addressof(host)
+            for i, (w, pw, transpose) in enumerate(ring):
+                O, I, kh, kw = w.shape
+                _l.check(lib.ffa_ring_pack_desc_fill(base + i * nb, w.data_ptr(), None, pw.data.data_ptr(), O, I,
+                                                     1 if transpose else 0, pw.rows, pw.ci_pitch, self.dtype_id),
+                         "ring_pack_desc_fill")
+                self.keep.append((w, pw))
+            self.table_ring = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
 
     def run(self) -> None:
         lib = _l.load()
-        _l.check(lib.ffa_pack_conv_weights_batched(self.dtype_id, self.table.data_ptr(), self.n, _stream()),
-                 "pack_conv_weights_batched")
+        if self.table is not None:
+            _l.check(lib.ffa_pack_conv_weights_batched(self.dtype_id, self.table.data_ptr(), self.n, _stream()),
+                     "pack_conv_weights_batched")
+        if self.table_ring is not None:
+            _l.check(lib.ffa_ring_pack_batched(self.dtype_id, self.table_ring.data_ptr(), self.n_ring, _stream()),
+                     "ring_pack_batched")
 
 
 def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:
@@ -162,7 +189,7 @@ def conv2d(x: torch.Tensor, w: PackedWeight, pad: int, out_channels: int, bias: 
     if bias is not None and bias.numel() < out_channels:
         raise ValueError("conv2d: bias shorter than the output pitch")
     if stats is not None:
-        if stats.dtype != torch.float32 or stats.numel() < conv_stat_rows(B, Ho, Wo) * 2 * out_channels:
+        if stats.dtype != torch.float32 or stats.numel() < conv_stat_rows(B, Ho, Wo, w) * 2 * out_channels:
             raise ValueError("conv2d: statistics buffer too small or not f32")
         _l.check(lib.ffa_conv2d_stats(_dt(x), x.data_ptr(), w.data.data_ptr(), _ptr(bias), _ptr(residual),
                                       out.data_ptr(), stats.data_ptr(), B, Hi, Wi, Ci, Ho, Wo, out_channels, w.rows,
@@ -172,6 +199,36 @@ def conv2d(x: torch.Tensor, w: PackedWeight, pad: int, out_channels: int, bias: 
     _l.check(lib.ffa_conv2d(_dt(x), x.data_ptr(), w.data.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
                             B, Hi, Wi, Ci, Ho, Wo, out_channels, w.rows, w.bco, w.kh, w.kw, w.stride, pad, dil,
                             1 if relu else 0, _stream()), "conv2d")
+    return out
+
+
+def conv3x3_ring(x: torch.Tensor, w: PackedWeight, out_channels: int, bias: Optional[torch.Tensor] = None,
+                 residual: Optional[torch.Tensor] = None, relu: bool = False, stats: Optional[torch.Tensor] = None,
+                 pro_scale: Optional[torch.Tensor] = None, pro_shift: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The ring kernel called directly (w must be a ring-layout operand): conv3x3 pad 1 of x, or -- with pro_scale /
+    pro_shift -- of relu(x * pro_scale[c] + pro_shift[c]) evaluated while the input is staged (the BatchNorm + ReLU
+    of the producing layer folded into this convolution, no normalised tensor in memory)."""
+    lib = _l.load()
+    _chk_nhwc(x, "conv input")
+    if not (w.bco & _l.BCO_RING):
+        raise ValueError("conv3x3_ring: operand is not in the ring layout")
+    B, H, W, Ci = x.shape
+    if Ci != w.ci_pitch:
+        raise ValueError(f"conv3x3_ring: input pitch {Ci} != packed pitch {w.ci_pitch}")
+    if out is None:
+        out = torch.empty((B, H, W, out_channels), dtype=x.dtype, device=x.device)
+    if stats is not None and (stats.dtype != torch.float32 or
+                              stats.numel() < conv_stat_rows(B, H, W, w) * 2 * out_channels):
+        raise ValueError("conv3x3_ring: statistics buffer too small or not f32")
+    if (pro_scale is None) != (pro_shift is None):
+        raise ValueError("conv3x3_ring: prologue needs scale and shift")
+    if pro_scale is not None and (pro_scale.numel() < Ci or pro_shift.numel() < Ci or
+                                  pro_scale.dtype != torch.float32 or pro_shift.dtype != torch.float32):
+        raise ValueError("conv3x3_ring: prologue vectors must be f32 with one entry per stored input channel")
+    _l.check(lib.ffa_ring_conv3x3(_dt(x), x.data_ptr(), w.data.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
+                                  _ptr(stats), _ptr(pro_scale), _ptr(pro_shift), B, H, W, Ci, out_channels, w.rows,
+                                  1 if relu else 0, _stream()), "ring_conv3x3")
     return out
 
 
@@ -269,8 +326,11 @@ def conv2d_dgrad_upcat(dy: torch.Tensor, wt: PackedWeight, c1: int, c2: int):
 FUSED_BN_STATS = os.environ.get("FFA_FUSED_BN_STATS", "1") != "0"
 
 
-def conv_stat_rows(B: int, Ho: int, Wo: int) -> int:
-    return int(_l.load().ffa_conv_stat_rows(B, Ho, Wo))
+def conv_stat_rows(B: int, Ho: int, Wo: int, w: Optional[PackedWeight] = None) -> int:
+    """rows of per-tile statistics the convolution with operand ``w`` writes (w=None: the conv_igemm tiling)"""
+    if w is None:
+        return int(_l.load().ffa_conv_stat_rows(B, Ho, Wo, 64, 64))
+    return int(_l.load().ffa_conv_stat_rows(B, Ho, Wo, w.rows, w.bco))
 
 
 def _bn_finalize(part: torch.Tensor, rows: int, npix: int, channels: int, gamma, beta, running_mean, running_var,
@@ -295,7 +355,7 @@ def conv2d_bn_stats(x: torch.Tensor, w: PackedWeight, pad: int, out_channels: in
         return (y0,) + tuple(bn_stats(y0, gamma, beta, running_mean, running_var, momentum, eps))
     B, Hi, Wi, _ = x.shape
     Ho, Wo = conv_out_size(Hi, w.kh, w.stride, pad), conv_out_size(Wi, w.kw, w.stride, pad)
-    rows = conv_stat_rows(B, Ho, Wo)
+    rows = conv_stat_rows(B, Ho, Wo, w)
     part = workspace(rows * 2 * out_channels * 4, x.device, "bnpart").view(torch.float32)
     y0 = conv2d(x, w, pad, out_channels, stats=part)
     return (y0,) + _bn_finalize(part, rows, B * Ho * Wo, out_channels, gamma, beta, running_mean, running_var,

@@ -45,6 +45,30 @@ const char* ffa_target_arch(void);
 
 /* preferred block height (output channels per workgroup) for a layer; weights are packed for it */
 int ffa_conv_block_co(int kh, int kw, int stride, int cout);
+/* Operand layout + block height of a layer: the `bco` value for ffa_pack_conv_weight / ffa_pack_desc_fill /
+ * ffa_conv2d / ffa_conv2d_stats / ffa_conv_stat_rows.  Bits 0..11 = rows per block (pad the row count to a multiple
+ * of it); FFA_BCO_RING set = the operand is packed for the LDS-DMA ring kernel (conv3x3_ring_kernel: 3x3 stride 1
+ * pad 1, >= 64 output channels, whole 64-byte groups of input channels).  Pass allow_ring = 0 for operands that feed
+ * ffa_conv2d_upcat / ffa_conv2d_dgrad_upcat / ffa_conv2d_bnbwd or a dil = 2 call.  The ring layout is opt-in:
+ * FFA_RING=1 in the environment (measured equal to / slightly behind the conv_igemm kernels). */
+#define FFA_BCO_RING 0x1000
+int ffa_conv_plan(int dtype, int kh, int kw, int stride, int cout, int ci_pitch, int allow_ring);
+/* The ring kernel called directly: out = relu?(conv3x3(in', w) + bias + residual) with in' = in, or -- when
+ * pro_scale / pro_shift are given -- in' = relu(in * pro_scale[c] + pro_shift[c]) evaluated while the input tile is
+ * staged (the training-mode BatchNorm + ReLU of the producing layer folded into this convolution's loader: replaces
+ * the F.batch_norm + relu pass between two convolutions of smp's Conv2dReLU / torchvision's BasicBlock; zero padding
+ * applies to the normalised tensor).  stat_partials as for ffa_conv2d_stats (rows = ffa_conv_stat_rows) or null. */
+int ffa_ring_conv3x3(int dtype, const void* in, const void* w_ring, const float* bias, const void* residual, void* out,
+                     float* stat_partials, const float* pro_scale, const float* pro_shift, int B, int H, int W, int Ci,
+                     int Co, int co_rows, int relu, ffa_stream_t stream);
+long long ffa_ring_stat_rows(int B, int H, int W, int co_rows);
+int ffa_ring_pack(int dtype, const float* w_oihw, const float* scale, void* dst, int O, int I, int transpose,
+                  int co_rows, int ci_pitch, ffa_stream_t stream);
+/* batched packing of ring operands (the ring layout has its own descriptor type) */
+int ffa_ring_pack_desc_bytes(void);
+int ffa_ring_pack_desc_fill(void* host_desc, const float* w_oihw, const float* scale, void* dst, int O, int I,
+                            int transpose, int co_rows, int ci_pitch, int dtype);
+int ffa_ring_pack_batched(int dtype, const void* descs_device, int n, ffa_stream_t stream);
 int ffa_conv_row_group(int kh);
 long long ffa_pack_conv_weight_bytes(int dtype, int co_rows, int ci_pitch, int kh, int kw);
 /* OIHW f32 master weight -> kernel operand.  transpose=1 builds the dgrad operand (rows = input
@@ -64,10 +88,10 @@ int ffa_conv2d(int dtype, const void* in, const void* w_packed, const float* bia
                int pad, int dil, int relu, ffa_stream_t stream);
 
 /* ffa_conv2d that also writes, per pixel tile, the channel sums and sums of squares of the output it stores:
- * stat_partials[rows][2][Co] f32, rows = ffa_conv_stat_rows(B, Ho, Wo).  With ffa_bn_finalize this replaces the
+ * stat_partials[rows][2][Co] f32, rows = ffa_conv_stat_rows(B, Ho, Wo, co_rows, bco).  With ffa_bn_finalize this replaces the
  * separate statistics pass of a training-mode BatchNorm that follows the convolution (torch.nn.functional.batch_norm
  * as called by smp's Conv2dReLU / torchvision's BasicBlock). */
-long long ffa_conv_stat_rows(int B, int Ho, int Wo);
+long long ffa_conv_stat_rows(int B, int Ho, int Wo, int co_rows, int bco);
 /* 1 when ffa_conv2d / ffa_conv2d_stats run this 3x3 stride-1 convolution on the persistent kernel
  * (conv3x3_persist_kernel, blocks that walk several pixel tiles; FFA_CONV_PERSIST=0 disables), else 0.
  * Profiling aid: the two kernels are separate symbols. */

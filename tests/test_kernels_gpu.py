@@ -447,7 +447,7 @@ def test_conv_epilogue_statistics_match_separate_pass(cuda, dtype, cin, cout, k,
     torch.cuda.synchronize()
     assert torch.equal(y, y_ref)
     if B * y.shape[1] * y.shape[2] > 1024 * 256:
-        assert ops.conv_stat_rows(B, y.shape[1], y.shape[2]) > 1024
+        assert ops.conv_stat_rows(B, y.shape[1], y.shape[2], pw) > 1024
     for name, a_, b_ in zip(("scale", "shift", "mean", "rstd"), got, ref):
         assert torch.allclose(a_[:cout], b_[:cout], rtol=2e-5, atol=2e-6), name
     assert torch.allclose(rm2[:cout], rm1[:cout], rtol=2e-5, atol=2e-7)
@@ -471,9 +471,9 @@ def test_conv_over_virtual_upsample_concat(cuda, dtype, c1, c2, cout, Hl, Wl):
     skip = to_nhwc(torch.randn(B, c2, 2 * Hl, 2 * Wl, generator=g), dtype, cuda, c2) if c2 else None
     w = (torch.randn(cout, c1 + c2, 3, 3, generator=g) / ((c1 + c2) * 9) ** 0.5).to(cuda)
     cop = ops.pad_channels(cout)
-    pw = ops.pack_conv_weight(w, dtype, 1, c1 + c2)
+    pw = ops.pack_conv_weight(w, dtype, 1, c1 + c2, allow_ring=False)
     cat = ops.upsample2x_concat_fwd(lo, skip)
-    rows = ops.conv_stat_rows(B, 2 * Hl, 2 * Wl)
+    rows = ops.conv_stat_rows(B, 2 * Hl, 2 * Wl, pw)
     st_ref = torch.zeros(rows * 2 * cop, device=cuda)
     st = torch.zeros(rows * 2 * cop, device=cuda)
     ref = ops.conv2d(cat, pw, 1, cop, stats=st_ref)
@@ -489,7 +489,7 @@ def test_conv_upcat_reports_unsupported_split(cuda):
     lo = torch.zeros(1, 4, 4, 16, device=cuda, dtype=torch.bfloat16)      # 16 channels < one 32-channel group
     skip = torch.zeros(1, 8, 8, 16, device=cuda, dtype=torch.bfloat16)
     w = torch.zeros(16, 32, 3, 3, device=cuda)
-    pw = ops.pack_conv_weight(w, torch.bfloat16, 1, 32)
+    pw = ops.pack_conv_weight(w, torch.bfloat16, 1, 32, allow_ring=False)
     assert ops.conv2d_upcat(lo, skip, pw, 16) is None
 
 
@@ -533,7 +533,7 @@ def test_dgrad_with_fused_upsample_concat_backward(cuda, dtype, c1, c2, cout, Hl
     cop = ops.pad_channels(cout)
     dy = to_nhwc(torch.randn(B, cout, 2 * Hl, 2 * Wl, generator=g), dtype, cuda, cop)
     w = (torch.randn(cout, c1 + c2, 3, 3, generator=g) / (cout * 9) ** 0.5).to(cuda)
-    pwt = ops.pack_conv_weight(w, dtype, 1, cop, transpose=True)
+    pwt = ops.pack_conv_weight(w, dtype, 1, cop, transpose=True, allow_ring=False)
     dcat = ops.conv2d(dy, pwt, 1, c1 + c2)
     dlo_ref, dskip_ref = ops.upsample2x_concat_bwd(dcat, c1)
     pair = ops.conv2d_dgrad_upcat(dy, pwt, c1, c2)
@@ -557,7 +557,7 @@ def test_bn_backward_reductions_from_dgrad_epilogue(cuda, dtype, cin, cout, H, W
     cip, cop = ops.pad_channels(cin), ops.pad_channels(cout)
     d2 = to_nhwc(torch.randn(B, cin, H, W, generator=g), dtype, cuda, cip)          # incoming gradient
     w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(cuda)      # acts as the dgrad operand
-    pw = ops.pack_conv_weight(w, dtype, 1, cip)
+    pw = ops.pack_conv_weight(w, dtype, 1, cip, allow_ring=False)
     x1 = to_nhwc(torch.randn(B, cout, H, W, generator=g), dtype, cuda, cop)          # pre-norm tensor of the BN
     gamma = (torch.rand(cop, generator=g) + 0.5).to(cuda)
     beta = (torch.randn(cop, generator=g) * 0.3).to(cuda)
@@ -640,8 +640,8 @@ def test_persistent_conv_equals_the_plain_kernel(cuda, dtype, cin, cout, H, W, g
     w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(cuda)
     bias = torch.randn(cop, generator=g).to(cuda)
     res = to_nhwc(torch.randn(B, cout, H, W, generator=g), dtype, cuda, cop)
-    pw = ops.pack_conv_weight(w, dtype, 1, cip)
-    rows = ops.conv_stat_rows(B, H, W)
+    pw = ops.pack_conv_weight(w, dtype, 1, cip, allow_ring=False)
+    rows = ops.conv_stat_rows(B, H, W, pw)
 
     def run():
         st = torch.zeros(rows * 2 * cop, device=cuda)
