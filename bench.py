@@ -55,6 +55,7 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []  # (symbol, flops, start, end)
+        self.hbm_records = []  # (symbol, algorithmic bytes, start, end): single-kernel HBM-bound launches
         self.enabled = False
 
     def install(self):
@@ -74,7 +75,9 @@ class KernelTimer:
             flops = 2.0 * B * (Ho * Wo / (dil * dil)) * w.rows_real * w.ch_real * w.kh * w.kw
             tile = "8x32" if Wo >= 32 else "16x16"
             dt = "bf16" if x.dtype == torch.bfloat16 else "f32"
-            if ops.conv_is_persistent(x.dtype, B, Ho, Wo, w, dil):  # blocks walking several tiles: its own symbol
+            if w.bco & 0x1000:  # ring-layout operand (FFA_RING=1): conv3x3_ring_kernel
+                sym = f"conv3x3_ring_kernel<{dt},{tile}{_hk_tag(w, x.dtype)}>"
+            elif ops.conv_is_persistent(x.dtype, B, Ho, Wo, w, dil):  # blocks walking several tiles: its own symbol
                 sym = f"conv3x3_persist_kernel<{dt},bco{w.bco},{tile}{_hk_tag(w, x.dtype)}>"
             else:
                 sym = f"conv_igemm_kernel<{dt},{w.kh}x{w.kw},s{w.stride},bco{w.bco},{tile}{_hk_tag(w, x.dtype)}>"
@@ -132,6 +135,55 @@ class KernelTimer:
         ops.conv2d, ops.conv_wgrad = conv2d, conv_wgrad
         ops.conv2d_dgrad_upcat, ops.conv2d_upcat = conv2d_dgrad_upcat, conv2d_upcat
 
+        # ---- HBM-bound kernels, one kernel per bracket (algorithmic bytes = every tensor read or written once) ----
+        orig_bn_apply, orig_sce = ops.bn_apply, ops.softmax_ce
+
+        def bn_apply(x, scale, shift, residual=None, relu=False, out=None):
+            if not timer.enabled:
+                return orig_bn_apply(x, scale, shift, residual, relu, out)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = orig_bn_apply(x, scale, shift, residual, relu, out)
+            e.record()
+            nb = x.numel() * x.element_size()
+            dt = "bf16" if x.dtype == torch.bfloat16 else "f32"
+            timer.hbm_records.append((f"bn_apply_kernel<{dt}>", nb * (3 if residual is not None else 2), s, e))
+            return y
+
+        def bn_bwd_stages(run_stage, x, has_y, has_dres):
+            nb = x.numel() * x.element_size()
+            dt = "bf16" if x.dtype == torch.bfloat16 else "f32"
+            if not timer.enabled:
+                run_stage(3)
+                return
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+            run_stage(1)  # channel_reduce_kernel<BnBwdOp> + the finalize kernel (a few microseconds)
+            ev[1].record()
+            ev[2].record()
+            run_stage(2)  # bn_bwd_apply_kernel alone
+            ev[3].record()
+            timer.hbm_records.append((f"channel_reduce_kernel<{dt},BnBwdOp>+finalize", nb * (3 if has_y else 2),
+                                      ev[0], ev[1]))
+            timer.hbm_records.append((f"bn_bwd_apply_kernel<{dt}>",
+                                      nb * ((3 if has_y else 2) + 1 + (1 if has_dres else 0)), ev[2], ev[3]))
+
+        def softmax_ce(logits, targets, *a, **kw):
+            if not timer.enabled:
+                return orig_sce(logits, targets, *a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_sce(logits, targets, *a, **kw)
+            e.record()
+            nb = logits.numel() * logits.element_size()
+            dt = "bf16" if logits.dtype == torch.bfloat16 else "f32"
+            # logits read + dlogits written (stored pitch), targets read + predictions written (1 B per pixel each)
+            timer.hbm_records.append((f"softmax_ce_kernel<{dt}>(+weight sum)", 2 * nb + 2 * targets.numel(), s, e))
+            return r
+
+        ops.bn_apply, ops.softmax_ce = bn_apply, softmax_ce
+        ops.BN_BWD_STAGE_HOOK = bn_bwd_stages
+
     def summary(self):
         agg = defaultdict(lambda: [0.0, 0.0, 0])
         for sym, flops, s, e in self.records:
@@ -141,16 +193,36 @@ class KernelTimer:
             a[2] += 1
         return {k: {"flops": v[0], "seconds": v[1], "launches": v[2]} for k, v in agg.items()}
 
+    def hbm_summary(self):
+        agg = defaultdict(lambda: [0.0, 0.0, 0])
+        for sym, nbytes, s, e in self.hbm_records:
+            a = agg[sym]
+            a[0] += nbytes
+            a[1] += s.elapsed_time(e) * 1e-3
+            a[2] += 1
+        return {k: {"bytes": v[0], "seconds": v[1], "launches": v[2]} for k, v in agg.items()}
+
 
 def pmc_traffic(symbol: str):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE are
     collected in their own rocprofv3 runs, never together with timing): profiles/r01_pmc_traffic.json.
     Returns None when no counter run matches the symbol."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
+    import glob
     import re
-    kernels = json.load(open(path))["kernels"]
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    if not found:
+        return None
+    kernels = json.load(open(found[-1]))["kernels"]  # the newest round's counter passes
+    mh = re.match(r"(bn_apply_kernel|bn_bwd_apply_kernel|softmax_ce_kernel)<(bf16|f32)>", symbol)
+    if mh:
+        want = "void {}<{}>".format(mh.group(1), "ffa_bf16" if mh.group(2) == "bf16" else "float")
+        hit = [v for name, v in kernels.items() if name.startswith(want)]
+        return round(hit[0]["hbm_bytes_per_launch"]) if hit else None
+    mr = re.match(r"conv3x3_ring_kernel<(bf16|f32),(\d+)x(\d+)", symbol)
+    if mr:
+        want = "void conv3x3_ring_kernel<{}, ".format("ffa_bf16" if mr.group(1) == "bf16" else "float")
+        hit = [v for name, v in kernels.items() if name.startswith(want) and f", {mr.group(2)}, {mr.group(3)}, " in name]
+        return round(max(hit, key=lambda v: v["launches"])["hbm_bytes_per_launch"]) if hit else None
     mp = re.match(r"conv3x3_persist_kernel<(bf16|f32),bco(\d+),(\d+)x(\d+),hk(\d)>", symbol)
     if mp:  # template arguments <T, BCO, TH, TW, HK>
         want = "void conv3x3_persist_kernel<{}, {}, {}, {}, {}>".format(
@@ -181,8 +253,8 @@ def pmc_traffic(symbol: str):
     return None if best is None else round(best["hbm_bytes_per_launch"])
 
 
-def cpu_baseline(budget_s: float = 25.0):
-    """The oracle's training step on the host cores (fp32, NCHW, eager, AdamW): B=2 tiles per step."""
+def cpu_baseline(budget_s: float = 14.0, B: int = 2):
+    """The oracle's training step on the host cores (fp32, NCHW, eager, AdamW): B tiles per step."""
     import torch.nn.functional as F
     from oracle.unet_resnet34 import UnetResNet34
     # the GPU box gives one GPU's share of the host: 16 cores (more threads than that oversubscribe the cgroup)
@@ -195,7 +267,6 @@ def cpu_baseline(budget_s: float = 25.0):
     torch.manual_seed(2025)
     model = UnetResNet34(5, 19).train()
     opt = torch.optim.AdamW(model.parameters(), lr=5e-5, weight_decay=0.01, betas=(0.9, 0.999))
-    B = 2
     x = torch.randn(B, 5, 512, 512)
     t = torch.randint(0, 19, (B, 512, 512))
     w = torch.tensor([1.0] * 15 + [0.0] * 4)
@@ -223,6 +294,7 @@ def cpu_baseline(budget_s: float = 25.0):
                     break
     except OSError:
         pass
+    del model, opt
     return {"value": round(B * n / dt, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
             "sample": f"{n} timed step(s) of batch {B} (512x512x5, 19 classes, fp32 NCHW eager, AdamW) after 1 warm-up; "
                       f"oracle/unet_resnet34.py on '{cpu_model}'"}
@@ -355,6 +427,11 @@ def main():
     # roofline pass: the same step run eagerly a few times with HIP events around every MFMA kernel launch (all ranks
     # take part: the eager step of a multi-process run contains the gradient all-reduce)
     final_loss_t = loss.detach().clone()
+    # nothing may keep the replayed step's autograd graph alive into the eager pass: its AccumulateGrad nodes belong
+    # to the capture stream (the stream-mismatch warning of round 1, and the capture hazard trainers.py documents)
+    del loss
+    if graphed is not None:
+        graphed.loss = graphed.loss.detach()
     roof_steps = 3
     timer.enabled = True
     for i in range(roof_steps):
@@ -398,8 +475,26 @@ def main():
             "final_loss": round(final_loss, 5), "hip_graph": bool(use_graph),
             "roofline": roofline,
         }
+        hsum = timer.hbm_summary()
+        if hsum:
+            hd = max(hsum.items(), key=lambda kv: kv[1]["seconds"])
+            gbs = hd[1]["bytes"] / hd[1]["seconds"] / 1e9
+            out["roofline_hbm"] = {
+                "bound": "hbm", "kernel": hd[0], "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(gbs / 8000.0, 4), "peak_measured_copy": 6290.0,
+                "frac_of_measured_copy": round(gbs / 6290.0, 4), "traffic": pmc_traffic(hd[0]),
+                "launches_per_step": hd[1]["launches"] / roof_steps,
+                "avg_launch_ms": round(hd[1]["seconds"] / hd[1]["launches"] * 1e3, 4),
+                "algorithmic_bytes_per_launch": round(hd[1]["bytes"] / hd[1]["launches"]),
+                "hbm_kernels_share_of_step": round(sum(v["seconds"] for v in hsum.values()) *
+                                                   (args.steps / roof_steps) / elapsed, 4)}
+            if args.breakdown:
+                for k, v in sorted(hsum.items(), key=lambda kv: -kv[1]["seconds"]):
+                    print(f"  {k:62s} {v['seconds'] / roof_steps * 1e3:8.3f} ms/step {v['launches'] // roof_steps:4d} "
+                          f"launches {v['bytes'] / v['seconds'] / 1e9:8.0f} GB/s", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(B=2)
+            out["cpu_baseline_b8"] = cpu_baseline(B=8)  # B = 2 (config 1) and B = 8
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

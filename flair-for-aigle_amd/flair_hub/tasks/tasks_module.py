@@ -100,7 +100,8 @@ class SegmentationTask(nn.Module):
 
     def _compute_aux_loss(self, dict_logits_aux, task, targets):
         # The reference tests `task in dict_logits_aux` against keys 'aux_<mod>_<task>' (tasks_module.py:180),
-        # which never matches, so its auxiliary term is always 0; aux decoders are not built here either.
+        # which never matches, so its auxiliary term is always 0 (the aux decoders are built and run, their logits
+        # just never reach the loss).
         return 0.0
 
     def _check_for_invalid_loss(self, loss, task, is_aux: bool = False):
@@ -128,8 +129,19 @@ class SegmentationTask(nn.Module):
             if self.global_step == self._warmup_scheduler.total_steps:
                 self._using_plateau = True
 
+    def _sync_metrics(self, metrics) -> None:
+        """Sum the metric state over the data-parallel ranks before it is read -- the reference gets this from
+        torchmetrics' state synchronisation and ``sync_dist=True`` (flair_hub/tasks/tasks_module.py:215-236,296-300).
+        Without it every rank would log (and schedule its learning rate on) the score of its own shard."""
+        from flairhip.distributed import all_reduce_sum_
+        tensors = []
+        for m in metrics:
+            tensors += [m.confmat] if hasattr(m, "confmat") else [m.total, m.count]
+        all_reduce_sum_(tensors)
+
     def on_train_epoch_end(self):
         self._report_invalid_loss()
+        self._sync_metrics(list(self.train_metrics.values()) + [self.train_loss])
         for task, metric in self.train_metrics.items():
             self.log(f"train_miou_{task.split('-')[-1]}", metric.compute())
             metric.reset()
@@ -147,6 +159,7 @@ class SegmentationTask(nn.Module):
 
     def on_validation_epoch_end(self):
         self._report_invalid_loss()
+        self._sync_metrics(list(self.val_metrics.values()) + list(self.val_iou.values()) + [self.val_loss])
         self.log("val_loss", self.val_loss.compute())
         mious = []
         for task in self.val_metrics:

@@ -16,7 +16,7 @@ from typing import Any, Dict, Iterable, Optional
 import torch
 import torch.distributed as dist
 
-from flairhip.distributed import GradSync
+from flairhip.distributed import GradSync, ShardedLoader, ensure_process_group
 
 logger = logging.getLogger(__name__)
 
@@ -84,16 +84,32 @@ class HipTrainer:
         self.hip_graph = bool(hip_graph)
         self.default_root_dir = default_root_dir
         self.monitor, self.monitor_mode = monitor, monitor_mode
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        # FFA_DIST_BACKEND=gloo rehearses several ranks on a one-GPU box: they then share cuda:0
+        ndev = max(torch.cuda.device_count(), 1)
+        self.device = torch.device("cuda", local % ndev if os.environ.get("FFA_DIST_BACKEND") == "gloo" else local)
+        # Lightning's DDP strategy sets the process group up itself (reference trainers.py:81-91 only names the
+        # strategy); under torchrun (WORLD_SIZE > 1) so does this trainer, before anything collective happens
+        ensure_process_group(self.device)
         self.world_size = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
-        local = int(os.environ.get("LOCAL_RANK", "0"))
-        self.device = torch.device("cuda", local)
+        if devices not in (None, "auto") and int(devices) * int(num_nodes) > 1 and self.world_size == 1:
+            raise RuntimeError(f"HipTrainer: {devices} device(s) x {num_nodes} node(s) requested but this is a single "
+                               "process: launch one process per GPU with `python -m torch.distributed.run "
+                               "--nproc-per-node N ...` (the trainer never spawns ranks itself)")
+        self.seed = int(unused.get("seed", 0))
         self.estimated_stepping_batches = 0
         self.callback_metrics: Dict[str, Any] = {}
         self.best_model_path = None
         self.optimizers = []
 
     # ---- fit -------------------------------------------------------------------------------------
+
+    def _shard(self, loader, shuffle=None, drop_last=True):
+        """the rank's share of a loader (what Lightning's DistributedSampler injection does under DDP)"""
+        if loader is None or self.world_size == 1 or isinstance(loader, ShardedLoader):
+            return loader
+        return ShardedLoader(loader, self.rank, self.world_size, shuffle=shuffle, seed=self.seed, drop_last=drop_last)
 
     def fit(self, model, datamodule=None, train_dataloaders: Optional[Iterable] = None,
             val_dataloaders: Optional[Iterable] = None) -> None:
@@ -104,6 +120,8 @@ class HipTrainer:
             datamodule.setup("fit")
             train_dataloaders = datamodule.train_dataloader()
             val_dataloaders = datamodule.val_dataloader() if hasattr(datamodule, "val_dataloader") else None
+        train_dataloaders = self._shard(train_dataloaders, drop_last=True)
+        val_dataloaders = self._shard(val_dataloaders, shuffle=False, drop_last=False)
         steps_per_epoch = len(train_dataloaders)
         self.estimated_stepping_batches = self.max_steps or steps_per_epoch * self.max_epochs
 
@@ -123,6 +141,8 @@ class HipTrainer:
         graphed, graph_sig, loss = None, None, None
         for epoch in range(self.max_epochs):
             model.train()
+            if isinstance(train_dataloaders, ShardedLoader):
+                train_dataloaders.set_epoch(epoch)  # a new shared permutation per epoch, as Lightning does
             for i, batch in enumerate(DevicePrefetcher(train_dataloaders, self.device)):
                 if use_graph and graphed is None and model.global_step >= 2:
                     # two ordinary steps first: they size every workspace, fill the weight-pack plan and create the
@@ -184,6 +204,7 @@ class HipTrainer:
         if datamodule is not None:
             datamodule.setup("validate")
             dataloaders = datamodule.val_dataloader()
+        dataloaders = self._shard(dataloaders, shuffle=False, drop_last=False)
         model.eval()
         for i, batch in enumerate(dataloaders):
             model.validation_step(_to_device(batch, self.device), i)
@@ -198,6 +219,7 @@ class HipTrainer:
         if datamodule is not None:
             datamodule.setup("predict")
             dataloaders = datamodule.predict_dataloader()
+        dataloaders = self._shard(dataloaders, shuffle=False, drop_last=False)  # every rank predicts its own share
         model.eval()
         outs = []
         for i, batch in enumerate(dataloaders):

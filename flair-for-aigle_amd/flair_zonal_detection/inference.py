@@ -54,9 +54,22 @@ def prep_config(config_path: str, model_ckpt_path: Optional[str] = None, model_t
     (scripts/run_fast_aigle_segmentation.py:75) and upstream FLAIR-HUB's one-argument call."""
     config = load_config(config_path) if isinstance(config_path, str) else config_path
     if images_folder is not None:
-        rasters = sorted(glob.glob(os.path.join(images_folder, "*.jp2")))
+        # the fork's caller feeds BD ORTHO JPEG-2000 tiles (scripts/run_fast_aigle_segmentation.py:88); JPEG-2000
+        # needs GDAL (rasterio) -- without it only GeoTIFF rasters can be opened (geotiff.py), so say so HERE instead
+        # of globbing *.jp2 and failing at the first read
+        try:
+            import rasterio  # type: ignore  # noqa: F401
+            patterns = ("*.jp2", "*.tif", "*.tiff")
+        except ImportError:
+            patterns = ("*.tif", "*.tiff")
+            if glob.glob(os.path.join(images_folder, "*.jp2")):
+                logger.warning("%s holds JPEG-2000 rasters, which need rasterio / GDAL (not installed): only "
+                               "GeoTIFF inputs are considered", images_folder)
+        rasters = sorted(p for pat in patterns for p in glob.glob(os.path.join(images_folder, pat)))
         if not rasters:
-            raise FileNotFoundError(f"no *.jp2 raster in {images_folder}")
+            raise FileNotFoundError(f"no raster ({', '.join(patterns)}) in {images_folder}"
+                                    + ("" if "*.jp2" in patterns else
+                                       "; JPEG-2000 inputs need rasterio, which is not installed"))
         config["modalities"]["AERIAL_RGBI"]["input_img_path"] = rasters[0]
     if model_ckpt_path is not None:
         config = overwrite_config(config, model_ckpt_path, model_threshold_filepath, result_folder, log_folder)
@@ -146,7 +159,9 @@ def init_outputs(config: Dict, ref_img, i=None) -> Tuple[Dict[str, object], Dict
                 import rasterio  # type: ignore
             except ImportError:
                 rasterio = None
-            if rasterio is None:  # no GDAL: the built-in GeoTIFF writer (tiled, LZW, written on close())
+            # a sharded run joins per-rank part files + "written" masks (geotiff.merge_shard_files): that protocol
+            # belongs to the built-in writer, so it is used for the parts even where rasterio is installed
+            if rasterio is None or config.get("shard") is not None:  # tiled, LZW, written on close()
                 from flair_zonal_detection.geotiff import GeoTiffWriter
                 os.makedirs(config["output_path"], exist_ok=True)
                 outputs[task["name"]] = GeoTiffWriter.like(path, ref_img, count, np.uint8, width=w, height=h,
@@ -164,14 +179,35 @@ def init_outputs(config: Dict, ref_img, i=None) -> Tuple[Dict[str, object], Dict
     return outputs, paths
 
 
+def _zoom_index(n: int, scale: float):
+    """Source index of every output position of ``scipy.ndimage.zoom(x, scale, order=0)`` along an axis of length
+    n, or -1 where scipy writes its constant 0 (reference inference.py:212-226 calls zoom with the default
+    mode='constant', grid_mode=False).  scipy maps output i to the input coordinate cc = i * (n - 1) / (out - 1),
+    out = round(n * scale), in float64, takes floor(cc + 0.5) for order 0 and treats cc > n - 1 -- which float
+    rounding produces for the LAST position of some (n, scale) pairs, e.g. n = 226, scale 0.5 -- as outside the
+    array.  Checked against scipy on 1.8 M positions (tests/test_oracle_goldens.py)."""
+    import math
+    out = int(round(n * scale))
+    step = (n - 1) / (out - 1) if out > 1 else 1.0
+    idx = []
+    for i in range(out):
+        cc = i * step
+        idx.append(-1 if (cc < 0.0 or cc > n - 1) else int(math.floor(cc + 0.5)))
+    return idx
+
+
 def _nearest_zoom(pred: torch.Tensor, scale: float) -> torch.Tensor:
-    """scipy.ndimage.zoom(order=0) semantics on the last two axes (reference :212-226): output size
-    round(n * scale), source index = floor of the centre-aligned coordinate scipy uses for order 0."""
+    """scipy.ndimage.zoom(order=0) on the last two axes, position for position (resample_prediction, reference
+    inference.py:212-226)."""
     h, w = pred.shape[-2:]
-    oh, ow = int(round(h * scale)), int(round(w * scale))
-    ys = torch.clamp(torch.round(torch.arange(oh, device=pred.device) * ((h - 1) / max(oh - 1, 1))).long(), 0, h - 1)
-    xs = torch.clamp(torch.round(torch.arange(ow, device=pred.device) * ((w - 1) / max(ow - 1, 1))).long(), 0, w - 1)
-    return pred[..., ys, :][..., xs]
+    ys = torch.tensor(_zoom_index(h, scale), dtype=torch.long, device=pred.device)
+    xs = torch.tensor(_zoom_index(w, scale), dtype=torch.long, device=pred.device)
+    out = pred[..., ys.clamp(min=0), :][..., xs.clamp(min=0)]
+    if bool((ys < 0).any()) or bool((xs < 0).any()):
+        out = out.clone()
+        out[..., ys < 0, :] = 0
+        out[..., xs < 0] = 0
+    return out
 
 
 @torch.no_grad()
@@ -298,12 +334,13 @@ def merge_shard_outputs(outputs_by_rank):
     return merged
 
 
-def run_inference(config_path, ref_raster=None, geozone=None, shard: Optional[Tuple[int, int]] = None
-                  ) -> Dict[str, object]:
+def run_inference(config_path, ref_raster=None, geozone=None, shard: Optional[Tuple[int, int]] = None,
+                  before_loop=None) -> Dict[str, object]:
     """End-to-end zonal run with upstream FLAIR-HUB's one-argument semantics (the fork's own run_inference is
     stale: inference.py:650-665 calls its helpers with the wrong arity).  Returns the output rasters.
     ``shard=(rank, world)`` (or config['shard']) restricts the run to that rank's slice of the tile grid: one process
-    per GPU, no communication; in-memory outputs then track their writes for merge_shard_outputs."""
+    per GPU, no communication; in-memory outputs then track their writes for merge_shard_outputs.  ``before_loop``
+    (optional) is called with the freshly initialised outputs before the first tile is processed."""
     t0 = time.time()
     config = prep_config(config_path)
     ref_path = config["modalities"][config["reference_modality"]]["input_img_path"]
@@ -322,6 +359,8 @@ def run_inference(config_path, ref_raster=None, geozone=None, shard: Optional[Tu
         loader = DataLoader(dataset, batch_size=config.get("batch_size", 8), num_workers=config.get("num_worker", 0),
                             pin_memory=True)
     outputs, _ = init_outputs(config, ref_img)
+    if before_loop is not None:
+        before_loop(outputs)
     if shard is not None:
         for o in outputs.values():
             if isinstance(o, ArrayRaster):

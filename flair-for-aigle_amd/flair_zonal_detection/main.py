@@ -27,10 +27,21 @@ sys.path.append(os.path.abspath(os.path.join(os.path.dirname(__file__), "../")))
 logger = logging.getLogger(__name__)
 
 
-def _wait_for(paths, timeout_s: float) -> None:
+def _remove_stale_parts(outputs) -> None:
+    """called by run_inference once the outputs exist, before the tile loop: drop this rank's leftovers"""
+    from flair_zonal_detection.geotiff import WRITTEN_SUFFIX
+    for o in outputs.values():
+        path = getattr(o, "path", None)
+        if path:
+            for f in (path, path + WRITTEN_SUFFIX):
+                if os.path.exists(f):
+                    os.remove(f)
+
+
+def _wait_for(paths, timeout_s: float, newer_than: float = 0.0) -> None:
     t0 = time.time()
     while True:
-        missing = [p for p in paths if not os.path.exists(p)]
+        missing = [p for p in paths if not (os.path.exists(p) and os.path.getmtime(p) >= newer_than)]
         if not missing:
             return
         if time.time() - t0 > timeout_s:
@@ -47,7 +58,11 @@ def run_sharded(config, rank: int, world: int, timeout_s: float = 3600.0, keep_p
     from flair_zonal_detection.inference import run_inference
     if torch.cuda.is_available():
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count())
-    outputs = run_inference(config, shard=(rank, world))
+    # The only synchronisation between ranks is the appearance of part files, so files an earlier (crashed, or
+    # --keep-parts) run left under the same names must not be mistaken for this run's: every rank removes its own
+    # part + mask before it starts, and rank 0 only accepts parts at least as new as its own start.
+    t_start = time.time()
+    outputs = run_inference(config, shard=(rank, world), before_loop=_remove_stale_parts)
     for task, o in outputs.items():
         if not isinstance(o, GeoTiffWriter):
             raise TypeError("a sharded multi-process run needs file outputs (GeoTIFF paths), not in-memory rasters")
@@ -58,7 +73,9 @@ def run_sharded(config, rank: int, world: int, timeout_s: float = 3600.0, keep_p
         mine = o.path  # <base>.r0of<world>.tif
         base = mine[:-len(f".r0of{world}.tif")]
         parts = [f"{base}.r{r}of{world}.tif" for r in range(world)]
-        _wait_for([p + WRITTEN_SUFFIX for p in parts], timeout_s)  # the mask is written after its part file
+        # the mask is written after its part file; ranks start together (torchrun), so a mask older than this
+        # rank's start (minus a generous clock / start-up skew) is a leftover that its owner has not replaced yet
+        _wait_for([p + WRITTEN_SUFFIX for p in parts], timeout_s, newer_than=t_start - 600.0)
         merged[task] = merge_shard_files(parts, base + ".tif")
         if not keep_parts:
             for p in parts:

@@ -74,6 +74,7 @@ SIGNATURES = {
     "ffa_bn_eval_params": (_i, [_i, _p, _p, _p, _p, _f, _p, _p, _p]),
     "ffa_bn_apply": (_i, [_i, _p, _p, _p, _p, _p, _ll, _i, _i, _p]),
     "ffa_bn_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p, _ll, _p]),
+    "ffa_bn_bwd_stages": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p, _ll, _i, _p]),
     "ffa_bn_bwd_fused": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p, _ll, _p, _p]),
     "ffa_channel_sums": (_i, [_i, _p, _ll, _i, _p, _p, _p, _ll, _p]),
     "ffa_maxpool3x3s2_fwd": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _p]),

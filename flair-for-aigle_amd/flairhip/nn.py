@@ -22,6 +22,17 @@ def _as_nhwc_grad(g: torch.Tensor) -> torch.Tensor:
     return g if g.is_contiguous() else g.contiguous()
 
 
+def _dw_out(conv) -> Optional[torch.Tensor]:
+    """Where the weight gradient of ``conv`` should be written: its slot in the data-parallel gradient bucket
+    (flairhip.distributed.GradSync) when there is one and no gradient has been accumulated yet -- autograd then adopts
+    the returned tensor as ``weight.grad`` and the all-reduce reads it in place -- else None (a fresh tensor)."""
+    w = conv.weight
+    buf = getattr(w, "_ffa_grad_buf", None)
+    if buf is None or w.grad is not None or buf.shape != w.shape:
+        return None
+    return buf.view(buf.shape)  # a fresh alias: autograd only adopts a gradient tensor nobody else holds
+
+
 class HipConv2d(nn.Module):
     """Parameter holder mirroring nn.Conv2d (weight OIHW f32, optional bias)."""
 
@@ -149,12 +160,19 @@ class HipBatchNorm2d(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self._pending_batches = 0
         self._register_state_dict_hook(HipBatchNorm2d._flush_hook)
+        self.register_load_state_dict_post_hook(HipBatchNorm2d._loaded_hook)
 
     def note_batch(self) -> None:
         self._pending_batches += 1  # folded into the device counter lazily (no per-step launch)
         # the running statistics were just rewritten through raw pointers (no tensor version moved): eval-mode folds
         # of THIS layer computed earlier are stale even if no optimizer step follows (statistics recalibration passes)
         self._stats_epoch = getattr(self, "_stats_epoch", 0) + 1
+
+    @staticmethod
+    def _loaded_hook(module, incompatible_keys):
+        # the loaded num_batches_tracked is the truth: batches counted before the load must not be added on top
+        module._pending_batches = 0
+        module._stats_epoch = getattr(module, "_stats_epoch", 0) + 1  # eval-mode folds of the old statistics are stale
 
     @staticmethod
     def _flush_hook(module, state_dict, prefix, local_metadata):
@@ -202,7 +220,7 @@ class _ConvBnAct(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             dw = ops.conv_wgrad(x, d0, conv.out_channels, conv.in_channels, conv.kernel_size, conv.kernel_size,
-                                conv.stride, conv.padding)
+                                conv.stride, conv.padding, out=_dw_out(conv))
         return dx, dw, dgamma, dbeta, dres, None, None, None
 
 
@@ -238,7 +256,7 @@ class _UpConvBnAct(torch.autograd.Function):
             dlo, dskip = pair
         dw = None
         if ctx.needs_input_grad[2]:
-            dw = ops.conv_wgrad_upcat(lo, skip, d0, conv.out_channels)
+            dw = ops.conv_wgrad_upcat(lo, skip, d0, conv.out_channels, out=_dw_out(conv))
             if dw is None:
                 raise RuntimeError("conv_wgrad_upcat refused a channel split that upcat_supported accepted")
         return dlo, dskip, dw, dgamma, dbeta, None, None
@@ -271,7 +289,8 @@ class _DecoderBlock(torch.autograd.Function):
         blk = ctx.blk
         ca, cb = blk.conv1[0], blk.conv2[0]
         db_, _, dgb, dbb = ops.bn_bwd(xb, _as_nhwc_grad(dy), None, gb, bb, mb, rb, True, False)
-        dwb = ops.conv_wgrad(ya, db_, cb.out_channels, cb.in_channels, 3, 3, 1, 1) if ctx.needs_input_grad[5] else None
+        dwb = (ops.conv_wgrad(ya, db_, cb.out_channels, cb.in_channels, 3, 3, 1, 1, out=_dw_out(cb))
+               if ctx.needs_input_grad[5] else None)
         pbt = cb.packed(db_.dtype, transpose=True, ring=not ops.FUSED_BN_BWD)
         if ops.FUSED_BN_BWD:
             dya, part, rows = ops.conv2d_bnbwd(db_, pbt, 1, ya.shape[-1], xa, sca, sha)
@@ -289,7 +308,7 @@ class _DecoderBlock(torch.autograd.Function):
             dlo, dskip = pair
         dwa = None
         if ctx.needs_input_grad[2]:
-            dwa = ops.conv_wgrad_upcat(lo, skip, da, ca.out_channels)
+            dwa = ops.conv_wgrad_upcat(lo, skip, da, ca.out_channels, out=_dw_out(ca))
             if dwa is None:
                 raise RuntimeError("conv_wgrad_upcat refused a channel split that upcat_supported accepted")
         return dlo, dskip, dwa, dga, dba, dwb, dgb, dbb, None
@@ -346,7 +365,7 @@ class _BasicBlock(torch.autograd.Function):
 
         def wgrad(conv, inp, d):
             return ops.conv_wgrad(inp, d, conv.out_channels, conv.in_channels, conv.kernel_size, conv.kernel_size,
-                                  conv.stride, conv.padding)
+                                  conv.stride, conv.padding, out=_dw_out(conv))
 
         d2, dres, dg2, db2 = ops.bn_bwd(x2, dy, y, g2, b2, m2, r2, True, True)
         dw2 = wgrad(c2, y1, d2) if ctx.needs_input_grad[4] else None
@@ -398,7 +417,7 @@ class _ConvBias(torch.autograd.Function):
             dx = ops.conv2d(dy, pwt, k - 1 - conv.padding, x.shape[-1], dil=conv.stride,
                             out_hw=(x.shape[1], x.shape[2]))
         dw = ops.conv_wgrad(x, dy, conv.out_channels, conv.in_channels, conv.kernel_size, conv.kernel_size,
-                            conv.stride, conv.padding) if ctx.needs_input_grad[1] else None
+                            conv.stride, conv.padding, out=_dw_out(conv)) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             s, _ = ops.channel_sums(dy)

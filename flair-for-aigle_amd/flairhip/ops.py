@@ -50,13 +50,19 @@ def _chk_nhwc(t: torch.Tensor, name: str) -> None:
 
 
 _workspaces = {}
+_retired_workspaces = []
 
 
 def workspace(nbytes: int, device: torch.device, slot: str = "default") -> torch.Tensor:
-    """Grow-only scratch buffer per (device, slot); the library itself never allocates."""
+    """Grow-only scratch buffer per (device, slot); the library itself never allocates.  A buffer that is outgrown
+    stays alive (``_retired_workspaces``): captured hipGraphs (GraphedTrainStep, GraphedCall) have its raw pointer
+    baked into their kernel arguments, and the caching allocator would otherwise hand the freed block to another
+    tensor that later replays then scribble split-K partials and statistics over."""
     key = (device.index, slot)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _retired_workspaces.append(buf)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf
@@ -414,8 +420,8 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, co_real: int, ci_real: int, kh
     return out
 
 
-def conv_wgrad_upcat(lo: torch.Tensor, skip: Optional[torch.Tensor], dy: torch.Tensor, co_real: int
-                     ) -> Optional[torch.Tensor]:
+def conv_wgrad_upcat(lo: torch.Tensor, skip: Optional[torch.Tensor], dy: torch.Tensor, co_real: int,
+                     out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """dW [co_real, C1 + C2, 3, 3] of the conv over cat(nearest_x2(lo), skip); None when unsupported."""
     lib = _l.load()
     _chk_nhwc(lo, "wgrad lo")
@@ -428,7 +434,8 @@ def conv_wgrad_upcat(lo: torch.Tensor, skip: Optional[torch.Tensor], dy: torch.T
     if need < 0:
         return None
     ws = workspace(need, lo.device, "wgrad")
-    out = torch.empty((co_real, C1 + C2, 3, 3), dtype=torch.float32, device=lo.device)
+    if out is None:
+        out = torch.empty((co_real, C1 + C2, 3, 3), dtype=torch.float32, device=lo.device)
     rc = lib.ffa_conv_wgrad_upcat(did, lo.data_ptr(), _ptr(skip), dy.data_ptr(), out.data_ptr(), B, Hl, Wl, C1, C2, Co,
                                   co_real, 0, ws.data_ptr(), ws.numel(), _stream())
     if rc == _l.ERR_UNSUPPORTED:
@@ -501,6 +508,10 @@ def coop_barrier_failed(device=None) -> bool:
     return bool(t is not None and int(t[3].item()) != 0)
 
 
+# set by bench.py's roofline pass: called as hook(run_stage, x, has_y, has_dres) instead of the single ffa_bn_bwd call
+BN_BWD_STAGE_HOOK = None
+
+
 def bn_bwd(x: torch.Tensor, dy: torch.Tensor, y: Optional[torch.Tensor], gamma, beta, mean, rstd, relu: bool,
            want_dres: bool):
     """-> (dx, dres or None, dgamma, dbeta).  With relu and y=None the ReLU mask is recomputed from x
@@ -523,9 +534,14 @@ def bn_bwd(x: torch.Tensor, dy: torch.Tensor, y: Optional[torch.Tensor], gamma, 
             return dx, dres, dgb[0], dgb[1]
         if rc != _l.ERR_UNSUPPORTED:
             _l.check(rc, "bn_bwd_fused")
-    _l.check(lib.ffa_bn_bwd(_dt(x), x.data_ptr(), dy.data_ptr(), _ptr(y), _ptr(gamma), _ptr(beta), mean.data_ptr(),
-                            rstd.data_ptr(), dx.data_ptr(), _ptr(dres), dgb[0].data_ptr(), dgb[1].data_ptr(),
-                            x.numel() // C_, C_, mode, ws.data_ptr(), ws.numel(), _stream()), "bn_bwd")
+    args = (_dt(x), x.data_ptr(), dy.data_ptr(), _ptr(y), _ptr(gamma), _ptr(beta), mean.data_ptr(), rstd.data_ptr(),
+            dx.data_ptr(), _ptr(dres), dgb[0].data_ptr(), dgb[1].data_ptr(), x.numel() // C_, C_, mode, ws.data_ptr(),
+            ws.numel())
+    if BN_BWD_STAGE_HOOK is not None:  # measurement harness: the two stages as separate calls (same kernels)
+        BN_BWD_STAGE_HOOK(lambda stages: _l.check(lib.ffa_bn_bwd_stages(*args, stages, _stream()), "bn_bwd"),
+                          x, y is not None, dres is not None)
+    else:
+        _l.check(lib.ffa_bn_bwd(*args, _stream()), "bn_bwd")
     return dx, dres, dgb[0], dgb[1]
 
 

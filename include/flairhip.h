@@ -155,6 +155,13 @@ int ffa_bn_apply(int dtype, const void* x, const void* residual, void* y, const 
 int ffa_bn_bwd(int dtype, const void* x, const void* dy, const void* y, const float* gamma, const float* beta,
                const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, long long npix,
                int C, int relu, void* workspace, long long workspace_bytes, ffa_stream_t stream);
+/* ffa_bn_bwd in two calls: stages bit 0 = reduction + finalize (dgamma, dbeta and the apply coefficients, left in
+ * the workspace), bit 1 = apply (dx, dres) from the coefficients of a stage-1 call on the SAME workspace; 3 = both.
+ * Lets a harness bracket each kernel with its own events (bench.py's HBM roofline entry). */
+int ffa_bn_bwd_stages(int dtype, const void* x, const void* dy, const void* y, const float* gamma, const float* beta,
+                      const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta,
+                      long long npix, int C, int relu, void* workspace, long long workspace_bytes, int stages,
+                      ffa_stream_t stream);
 /* ffa_bn_bwd as ONE co-resident kernel (bf16): x and the masked dy stay in registers across two grid-wide barriers
  * -- three passes over memory instead of five, one launch instead of three.  sync = four uint32 of device memory,
  * zero before the first call and owned by the library afterwards (sync[3] != 0: a barrier timed out, results of

@@ -49,7 +49,7 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(1234 + rank)  # ranks start with DIFFERENT weights: GradSync must broadcast rank 0's
     net = Net()
-    sync = GradSync(net, bucket_bytes=100 * 1024)  # several buckets
+    sync = GradSync(net, bucket_bytes=100 * 1024, exact_unused=True)  # several buckets
     opt = torch.optim.SGD(net.parameters(), lr=0.05)
     for step in range(4):
         x, y = _data(rank, step)
@@ -96,3 +96,124 @@ def test_gradsync_gloo_world2(tmp_path):
         opt.step()
     for k, v in net.state_dict().items():
         assert torch.allclose(w0[k], v, rtol=1e-4, atol=1e-6), k
+
+
+# --------------------------------------------------------------------------------------------------
+# ranks whose backward differs from step to step (the model's modality dropout draws per rank:
+# flair_hub/models/flair_model.py:343-352): the sequence of collectives must not depend on it
+
+
+class BranchNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.enc_a = torch.nn.Linear(20, 200)
+        self.enc_b = torch.nn.Linear(20, 200)
+        self.head = torch.nn.Linear(200, 5)
+        self.never = torch.nn.Linear(3, 3)
+
+    def forward(self, x, use_a, use_b):
+        h = 0
+        if use_a:
+            h = h + torch.relu(self.enc_a(x))
+        if use_b:
+            h = h + torch.relu(self.enc_b(x))
+        return self.head(h)
+
+
+# (use_a, use_b) per (step, rank): different sub-modules skipped on different ranks in different steps, including
+# step 0 (where the bucket layout is learnt) and a branch that first gets a gradient after step 0
+BRANCHES = [[(True, False), (False, True)], [(True, True), (True, False)], [(False, True), (False, True)],
+            [(True, False), (True, True)]]
+
+
+def _branch_worker(rank, world, port, out_dir, exact):
+    sys.path.insert(0, os.path.join(ROOT, "flair-for-aigle_amd"))
+    from flairhip.distributed import GradSync
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(77 + rank)
+    net = BranchNet()
+    sync = GradSync(net, bucket_bytes=8 * 1024, exact_unused=exact)
+    opt = torch.optim.AdamW(net.parameters(), lr=0.01, weight_decay=0.1)
+    never0 = net.never.weight.detach().clone()
+    for step, per_rank in enumerate(BRANCHES):
+        ua, ub = per_rank[rank]
+        g = torch.Generator().manual_seed(10 * step + rank)
+        x, y = torch.randn(8, 20, generator=g), torch.randn(8, 5, generator=g)
+        loss = ((net(x, ua, ub) - y) ** 2).mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        sync.finish()
+        if exact:
+            assert net.never.weight.grad is None  # no rank produced one: left alone, as DDP does
+        else:
+            assert net.never.weight.grad is not None and float(net.never.weight.grad.abs().max()) == 0.0
+        opt.step()
+        torch.save(net.state_dict(), os.path.join(out_dir, f"w_{step}_{rank}.pt"))
+    if exact:
+        assert torch.equal(net.never.weight, never0)  # AdamW skipped it (no weight decay on a gradient-less tensor)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exact", [False, True], ids=["zero-fill", "exact-unused"])
+def test_gradsync_ranks_skip_different_submodules(tmp_path, exact):
+    world = 2
+    mp.spawn(_branch_worker, args=(world, _free_port(), str(tmp_path), exact), nprocs=world, join=True)
+    for step in range(len(BRANCHES)):
+        w0, w1 = (torch.load(tmp_path / f"w_{step}_{r}.pt") for r in range(world))
+        for k in w0:
+            assert torch.equal(w0[k], w1[k]), f"replicas diverged at step {step}, {k}"
+    # reference: mean over ranks with a missing gradient counted as zero
+    torch.manual_seed(77)
+    net = BranchNet()
+    opt = torch.optim.AdamW(net.parameters(), lr=0.01, weight_decay=0.1)
+    for step, per_rank in enumerate(BRANCHES):
+        sums = {}
+        for r in range(world):
+            g = torch.Generator().manual_seed(10 * step + r)
+            x, y = torch.randn(8, 20, generator=g), torch.randn(8, 5, generator=g)
+            net.zero_grad(set_to_none=True)
+            ((net(x, *per_rank[r]) - y) ** 2).mean().backward()
+            for k, p in net.named_parameters():
+                if p.grad is not None:
+                    sums[k] = sums.get(k, 0) + p.grad.clone()
+        for k, p in net.named_parameters():
+            if k in sums:
+                p.grad = sums[k] / world
+            else:
+                p.grad = None if exact else torch.zeros_like(p)
+        opt.step()
+        got = torch.load(tmp_path / f"w_{step}_0.pt")
+        for k, v in net.state_dict().items():
+            assert torch.allclose(got[k], v, rtol=1e-5, atol=1e-7), (step, k)
+
+
+def test_sharded_loader_covers_the_data_once():
+    sys.path.insert(0, os.path.join(ROOT, "flair-for-aigle_amd"))
+    from flairhip.distributed import ShardedLoader
+    from torch.utils.data import DataLoader, TensorDataset
+    world = 4
+    data = torch.arange(103)
+    # (a) DataLoader over a map-style dataset: DistributedSampler injection, shared permutation per epoch
+    seen = {0: [], 1: []}
+    for epoch in (0, 1):
+        for r in range(world):
+            ld = ShardedLoader(DataLoader(TensorDataset(data), batch_size=5, shuffle=True, drop_last=True), r, world,
+                               seed=3)
+            ld.set_epoch(epoch)
+            items = [int(v) for (b,) in ld for v in b]
+            assert len(items) == (103 // world // 5) * 5  # drop_last at both levels, same count on every rank
+            seen[epoch].append(items)
+        flat = [v for items in seen[epoch] for v in items]
+        assert len(set(flat)) == len(flat)  # no sample on two ranks
+    assert seen[0] != seen[1]  # set_epoch reshuffles
+    # (b) generic iterable of global batches: contiguous slices per rank
+    batches = [{"x": torch.arange(i * 8, i * 8 + 8), "ids": [str(j) for j in range(8)], "meta": 1} for i in range(3)]
+    batches.append({"x": torch.arange(24, 30), "ids": [str(j) for j in range(6)], "meta": 1})  # ragged last batch
+    for drop_last, want in ((True, 24), (False, 30)):
+        got = []
+        for r in range(world):
+            for b in ShardedLoader(batches, r, world, drop_last=drop_last):
+                assert len(b["ids"]) == b["x"].numel() and b["meta"] == 1
+                got += b["x"].tolist()
+        assert sorted(got) == list(range(want))

@@ -1,0 +1,95 @@
+"""N > 1 on the real product: two ranks of the HIP U-Net sharing the one GPU of the test box (gloo backend -- RCCL
+refuses two ranks on one device, and the product has no CPU path for the gloo CPU test to drive).  HipTrainer sets
+up the process group, shards the global batches, GradSync averages the gradients; the replicas must stay bit-identical
+and equal the single-process emulation "mean of the per-rank gradients, one optimizer step" (the Lightning DDP
+semantics of the reference: flair_hub/tasks/trainers.py:81-91, DistributedSampler + drop_last
+flair_hub/tasks/module_setup.py:40)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from helpers import ROOT, MOD, TASK
+
+pytestmark = pytest.mark.gpu
+
+STEPS, B_RANK, TILE, WORLD = 3, 2, 64, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _global_batches():
+    g = torch.Generator().manual_seed(5)
+    return [{MOD: torch.randn(WORLD * B_RANK, 5, TILE, TILE, generator=g),
+             TASK: torch.randint(0, 19, (WORLD * B_RANK, TILE, TILE), generator=g, dtype=torch.uint8)}
+            for _ in range(STEPS)]
+
+
+def _build(seed_shift=0):
+    from flairhip.configs import unet_resnet34_config
+    from flair_hub.tasks.module_setup import build_segmentation_module
+    cfg = unet_resnet34_config(in_channels=5, precision="bf16", batch_size=B_RANK, total_steps=STEPS)
+    torch.manual_seed(cfg["hyperparams"]["seed"] + seed_shift)
+    return build_segmentation_module(cfg, {MOD: TILE}, "train")
+
+
+def _worker(rank, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "flair-for-aigle_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(WORLD), FFA_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from flair_hub.tasks.trainers import HipTrainer
+    task = _build(seed_shift=rank)  # ranks start from DIFFERENT weights: rank 0's must win
+    trainer = HipTrainer(max_epochs=1, max_steps=STEPS)  # process group + sharding happen inside
+    assert trainer.world_size == WORLD and trainer.rank == rank
+    trainer.fit(task, train_dataloaders=_global_batches())
+    torch.cuda.synchronize()
+    torch.save({k: v.detach().cpu() for k, v in task.model.named_parameters()}, os.path.join(out_dir, f"w{rank}.pt"))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_the_mean_gradient_step(cuda, tmp_path):
+    mp.spawn(_worker, args=(_free_port(), str(tmp_path)), nprocs=WORLD, join=True)
+    w0, w1 = (torch.load(tmp_path / f"w{r}.pt") for r in range(WORLD))
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), f"replicas diverged at {k}"
+
+    # single-process emulation with rank 0's start weights
+    task = _build().to(cuda)
+    task.train()
+
+    class _T:  # what configure_optimizers reads from the trainer
+        estimated_stepping_batches = STEPS
+    task.trainer = _T()
+    opt_cfg = task.configure_optimizers()
+    opt, sched = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
+    params = dict(task.model.named_parameters())
+    for i, gb in enumerate(_global_batches()):
+        sums = {}
+        for r in range(WORLD):
+            sl = {k: v[r * B_RANK:(r + 1) * B_RANK].to(cuda) for k, v in gb.items()}
+            opt.zero_grad(set_to_none=True)
+            task.training_step(sl, i).backward()
+            for k, p in params.items():
+                if p.grad is not None:
+                    sums[k] = p.grad.clone() if k not in sums else sums[k] + p.grad
+        for k, p in params.items():
+            p.grad = sums[k] * (1.0 / WORLD) if k in sums else torch.zeros_like(p)
+        opt.step()
+        sched.step()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k, p in params.items():
+        d = (p.detach().cpu() - w0[k]).abs().max().item()
+        worst = max(worst, d / (w0[k].abs().max().item() + 1e-12))
+        assert torch.equal(p.detach().cpu(), w0[k]), f"{k}: data-parallel step differs from the mean-gradient step ({d})"

@@ -139,3 +139,78 @@ def test_full_size_training_step_is_deterministic(cuda):
     assert runs[0][1].keys() == runs[1][1].keys() and len(runs[0][1]) > 100
     for n, g0 in runs[0][1].items():
         assert torch.equal(g0, runs[1][1][n]), n
+
+
+def _grad_errors(task, oracle):
+    """relative L2 error of every parameter gradient of the product against the oracle's"""
+    osd = dict(oracle.named_parameters())
+    out = {}
+    for name, p in task.model.named_parameters():
+        if name.startswith("fusion_handler."):
+            continue
+        ok = ("encoder." if name.startswith("encoders.") else "") + name.split(".seg_model.", 1)[1]
+        rg = osd[ok].grad
+        out[name] = ((p.grad.float().cpu() - rg).norm() / (rg.norm() + 1e-12)).item()
+    return out
+
+
+def test_fp32_gradients_at_full_tile_size_match_the_oracle(cuda):
+    """Every parameter gradient of a TRAINING step on two full-size tiles (fp32 mode) against the oracle's autograd.
+    At 512 x 512 the bottleneck BatchNorms see 2 x 16 x 16 = 512 samples, so the 1e-2 budget the 64 x 96 test needs
+    (12 samples at the bottleneck amplify summation-order noise) must tighten by an order of magnitude here -- if it
+    did not, a kernel would be off, not the conditioning."""
+    task, oracle, _ = make_pair(precision="fp32")
+    x, t = _batch(2, seed=17)
+    oracle.train()
+    ref_loss = F.cross_entropy(oracle(x), t, weight=WEIGHTS)
+    ref_loss.backward()
+    task.train()
+    loss, _, _ = task.step({MOD: x.to(cuda), TASK: t.to(cuda)}, training=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref_loss.item()) <= 2e-5 * max(1.0, abs(ref_loss.item()))
+    errs = _grad_errors(task, oracle)
+    worst = max(errs, key=errs.get)
+    print(f"fp32 512x512 gradients: worst relative L2 error {errs[worst]:.3e} at {worst}; "
+          f"median {sorted(errs.values())[len(errs) // 2]:.3e}")
+    assert len(errs) > 100
+    assert errs[worst] <= 1e-3, f"{worst}: relative grad error {errs[worst]}"
+
+
+def test_bf16_at_full_tile_size_against_the_oracle(cuda):
+    """The benchmarked mode (bf16 storage, f32 accumulation) on two full-size tiles against the fp32 oracle: eval
+    logits / argmax, the training loss, and every parameter gradient.  Budgets are bf16 budgets: 8 mantissa bits per
+    stored activation, ~50 layers deep."""
+    task, oracle, _ = make_pair(precision="bf16")
+    x, t = _batch(2, seed=19)
+    batch = {MOD: x.to(cuda), TASK: t.to(cuda)}
+    oracle.eval()
+    with torch.no_grad():
+        ref = oracle(x)
+    task.eval()
+    with torch.no_grad():
+        got = task.model(batch)[0][TASK].float().cpu()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    agree = (got.argmax(1) == ref.argmax(1)).float().mean().item()
+    # the disagreeing pixels must be near-ties of the reference (top-2 margin within the bf16 error), not errors
+    top2 = ref.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1])[got.argmax(1) != ref.argmax(1)]
+    print(f"bf16 512x512 eval: relative logit error {rel:.3e}, argmax agreement {agree:.5f}, "
+          f"largest reference margin among disagreeing pixels {margin.max().item() if margin.numel() else 0:.3e}")
+    assert rel <= 0.03 and agree >= 0.97
+    if margin.numel():
+        assert margin.max().item() <= 0.25 * ref.abs().max().item()
+    oracle.train()
+    ref_loss = F.cross_entropy(oracle(x), t, weight=WEIGHTS)
+    ref_loss.backward()
+    task.train()
+    loss, _, _ = task.step(batch, training=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    lrel = abs(loss.item() - ref_loss.item()) / abs(ref_loss.item())
+    errs = _grad_errors(task, oracle)
+    worst = max(errs, key=errs.get)
+    print(f"bf16 512x512 train: loss {loss.item():.5f} vs {ref_loss.item():.5f} (rel {lrel:.2e}); gradients: worst "
+          f"relative L2 error {errs[worst]:.3e} at {worst}, median {sorted(errs.values())[len(errs) // 2]:.3e}")
+    assert lrel <= 5e-3
+    assert errs[worst] <= 0.15 and sorted(errs.values())[len(errs) // 2] <= 0.05

@@ -366,3 +366,22 @@ def test_configure_optimizers_variants_mirror_the_reference():
     task, _ = task_for(optimizer="lamb")
     with pytest.raises(ValueError):
         task.configure_optimizers()
+
+
+def test_nearest_zoom_index_equals_scipy():
+    """flair_zonal_detection.inference._zoom_index against scipy.ndimage.zoom(order=0) itself (what the reference's
+    resample_prediction calls, inference.py:212-226), including scipy's constant-0 last position on some sizes;
+    the scales are ref_res / output_px_meters pairs a config can produce (0.2 m -> 0.25, 0.3, 0.15, 0.4, 0.5, 0.8 m)."""
+    from scipy.ndimage import zoom
+    from flair_zonal_detection.inference import _zoom_index
+    scales = [0.5, 0.8, 2 / 3, 4 / 3, 1.25, 2, 4, 0.4, 0.25, 0.2 / 0.25, 0.2 / 0.3, 0.2 / 0.15, 0.2 / 0.5, 0.2 / 0.8, 3.0]
+    hit_constant = 0
+    for n in list(range(2, 700, 5)) + [226, 256, 432, 448, 512]:
+        for z in scales:
+            if int(round(n * z)) < 1:
+                continue
+            ref = zoom(np.arange(1, n + 1, dtype=np.int64), z, order=0)  # values 1..n: the constant 0 is visible
+            got = np.array([0 if k < 0 else k + 1 for k in _zoom_index(n, z)])
+            assert got.shape == ref.shape and np.array_equal(got, ref), (n, z)
+            hit_constant += int((ref == 0).any())
+    assert hit_constant > 0  # the quirk is exercised
