@@ -56,7 +56,10 @@ def test_graph_replay_matches_eager(cuda):
     assert le == lg, (le, lg)
     assert torch.equal(we, wg), ((we - wg).norm() / we.norm()).item()
     assert int(cg.sum()) == int(ce.sum()) + 2 * 2 * 64 * 64  # + the two warm-up batches
-    assert ng == ne + 2
+    # the warm-up batches were counted before task.load_state_dict(state) restored the pre-warm-up buffers: the
+    # loaded num_batches_tracked is the truth (HipBatchNorm2d drops its pending count on load), so both runs end
+    # with the four real batches
+    assert ng == ne
 
 
 def test_trainer_graph_mode_follows_the_eager_trainer(cuda):
