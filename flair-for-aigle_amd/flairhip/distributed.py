@@ -58,8 +58,12 @@ class _Bucket:
 
 class GradSync:
     def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20, process_group=None,
-                 broadcast_from_rank0: bool = True, hooks: bool = True, exact_unused: bool = False):
+                 broadcast_from_rank0: bool = True, hooks: bool = True, exact_unused: bool = False,
+                 always_sync: bool = False):
         self.group = process_group
+        # always_sync: run the bucket protocol (collectives included) even in a one-rank group -- a single GPU can
+        # then exercise the RCCL backend end to end (tests/test_distributed_gpu.py); normally a lone rank skips it
+        self.always_sync = always_sync
         self.exact_unused = exact_unused
         self._flags: Optional[torch.Tensor] = None
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -85,7 +89,7 @@ class GradSync:
         """rank 0's arrival order followed by the parameters it saw no gradient for -- identical on every rank"""
         seen = set(local_order)
         order = list(local_order) + [i for i in range(len(self.params)) if i not in seen]
-        if self.world > 1:
+        if self.world > 1 or self.always_sync:
             dev = self.params[0].device
             t = torch.tensor(order, dtype=torch.int64, device=dev if dev.type == "cuda" else "cpu")
             dist.broadcast(t, 0, group=self.group)
@@ -132,7 +136,7 @@ class GradSync:
             p.grad = view
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
-        if self.world == 1:
+        if self.world == 1 and not self.always_sync:
             return
         if self._buckets is None:
             self._fired_order.append(self._index[p])
@@ -155,14 +159,13 @@ class GradSync:
 
     def _launch(self, b: _Bucket) -> None:
         b.launched = True
-        if self.world > 1:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self) -> None:
         """Call after backward, before optimizer.step(): completes the step's collectives (zero-filling the slots of
         parameters that produced no gradient), waits for them (stream-side on RCCL, no host stall) and turns the
         sums into means.  Afterwards every parameter of the module has its mean gradient in ``p.grad``."""
-        if self.world == 1:
+        if self.world == 1 and not self.always_sync:
             return
         if self._buckets is None:  # first step: learn the arrival order, no overlap yet
             self._build_buckets(self._fired_order)

@@ -93,3 +93,56 @@ def test_two_ranks_on_one_gpu_match_the_mean_gradient_step(cuda, tmp_path):
         d = (p.detach().cpu() - w0[k]).abs().max().item()
         worst = max(worst, d / (w0[k].abs().max().item() + 1e-12))
         assert torch.equal(p.detach().cpu(), w0[k]), f"{k}: data-parallel step differs from the mean-gradient step ({d})"
+
+
+def _rccl_worker(rank, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "flair-for-aigle_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from flairhip.distributed import GradSync
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)  # backend "nccl" IS RCCL on ROCm
+    results = {}
+    for mode in ("plain", "rccl"):
+        task = _build().to(dev)
+        task.train()
+
+        class _T:
+            estimated_stepping_batches = STEPS
+        task.trainer = _T()
+        opt = task.configure_optimizers()["optimizer"]
+        sync = GradSync(task.model, always_sync=(mode == "rccl"))
+        for i, gb in enumerate(_global_batches()):
+            b = {k: v[:B_RANK].to(dev) for k, v in gb.items()}
+            loss = task.training_step(b, i)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            sync.finish()
+            opt.step()
+        if mode == "rccl":
+            assert sync._buckets is not None and len(sync._buckets) >= 3  # 24.4 M f32 parameters in 32 MiB buckets
+            # from step 1 on the weight gradients were written straight into the buckets: p.grad aliases its slot
+            w = task.model.encoders[MOD].seg_model.layer2[0].conv1.weight
+            assert w.grad.data_ptr() == sync._view(w).data_ptr()
+        torch.cuda.synchronize()
+        results[mode] = {k: v.detach().cpu() for k, v in task.model.named_parameters()}
+        sync.remove()
+    torch.save(results, os.path.join(out_dir, "rccl.pt"))
+    dist.destroy_process_group()
+
+
+def test_bucket_protocol_over_rccl_on_one_gpu(cuda, tmp_path):
+    """The collectives of the data-parallel step through the backend the product ships with: backend "nccl" = RCCL.
+    One GPU admits one RCCL rank, so the group has a single member (the sum over one rank is the identity): what
+    this executes for real is RCCL communicator set-up, the broadcast of the bucket order, the bucketed all-reduce
+    kernels launched from the autograd hooks underneath backward, the in-bucket gradient views and the stream-side
+    waits -- and the result must equal the same steps without any synchronisation, bit for bit."""
+    mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(tmp_path / "rccl.pt")
+    for k, v in res["plain"].items():
+        if k.startswith("fusion_handler."):
+            continue  # gradient-less: the synchronised run zero-fills them, AdamW then applies weight decay alone
+        assert torch.equal(v, res["rccl"][k]), k
