@@ -68,6 +68,14 @@ SIGNATURES = {
     "ffa_conv_wgrad": (_i, [_i, _p, _p, _p] + [_i] * 14 + [_p, _ll, _p]),
     "ffa_conv_wgrad_upcat": (_i, [_i, _p, _p, _p, _p] + [_i] * 8 + [_p, _ll, _p]),
     "ffa_conv_is_persistent": (_i, [_i] * 11),
+    "ffa_reflect_pad1": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
+    "ffa_group_norm": (_i, [_i, _p, _p, _p, _p, _p, _ll, _i, _ll, _ll, _i, _ll, _i, _i, _f, _i, _p]),
+    "ffa_positional_encoding": (_i, [_p, _p, _i, _i, _i, _f, _p]),
+    "ffa_add_rowvec": (_i, [_i, _p, _p, _i, _i, _i, _p]),
+    "ffa_ltae_attention": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "ffa_temporal_aggregate": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "ffa_detect_pad_images": (_i, [_p, _p, _i, _ll, _f, _p]),
+    "ffa_mask_images": (_i, [_i, _p, _p, _i, _ll, _f, _p]),
     "ffa_bn_workspace_bytes": (_ll, [_i]),
     "ffa_bn_stats": (_i, [_i, _p, _ll, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _ll, _p]),
     "ffa_bn_finalize": (_i, [_p, _ll, _ll, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _ll, _p]),

@@ -801,3 +801,107 @@ def write_window(left, top, img_bounds, out_res, pred_h: int, pred_w: int):
     _l.check(lib.ffa_write_window(float(left), float(top), float(il), float(ib), float(ir), float(it), float(out_res),
                                   int(pred_h), int(pred_w), C.byref(w)), "write_window")
     return w
+
+
+# --------------------------------------------------------------------------------------------------
+# U-TAE Sentinel branch (flair_hub/models/multitemp_model.py): small kernels around conv2d
+
+def reflect_pad1(x: torch.Tensor) -> torch.Tensor:
+    """[N,H,W,C] -> [N,H+2,W+2,C], reflect padding by one pixel (nn.Conv2d(padding_mode='reflect'))"""
+    _chk_nhwc(x, "reflect_pad1 input")
+    N, H, W, C = x.shape
+    out = torch.empty((N, H + 2, W + 2, C), dtype=x.dtype, device=x.device)
+    _l.check(_l.load().ffa_reflect_pad1(_dt(x), x.data_ptr(), out.data_ptr(), N, H, W, C, _stream()), "reflect_pad1")
+    return out
+
+
+def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, relu: bool = False,
+               residual: Optional[torch.Tensor] = None, eps: float = 1e-5) -> torch.Tensor:
+    """nn.GroupNorm over each image of an NHWC tensor: y = [residual +] relu?(gn(x))"""
+    _chk_nhwc(x, "group_norm input")
+    N, H, W, C = x.shape
+    y = torch.empty_like(x)
+    _l.check(_l.load().ffa_group_norm(_dt(x), x.data_ptr(), _ptr(residual), y.data_ptr(), gamma.data_ptr(),
+                                      beta.data_ptr(), N, 1, H * W * C, 0, H * W, C, C, groups, eps, 1 if relu else 0,
+                                      _stream()), "group_norm")
+    return y
+
+
+def group_norm_seq(x: torch.Tensor, B: int, T: int, gamma: torch.Tensor, beta: torch.Tensor, groups: int,
+                   eps: float = 1e-5) -> torch.Tensor:
+    """nn.GroupNorm over the T dates of every pixel: x is [B*T, h, w, C] (image n = b*T + t); statistics per
+    (b, pixel, group) over T x C/groups values (LTAE2d.in_norm / out_norm with T = 1)"""
+    _chk_nhwc(x, "group_norm_seq input")
+    N, h, w, C = x.shape
+    if N != B * T:
+        raise ValueError("group_norm_seq: leading size is not B * T")
+    y = torch.empty_like(x)
+    P = h * w
+    _l.check(_l.load().ffa_group_norm(_dt(x), x.data_ptr(), None, y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                      B * P, P, T * P * C, C, T, P * C, C, groups, eps, 0, _stream()), "group_norm")
+    return y
+
+
+def positional_encoding(pos: torch.Tensor, d: int, repeat: int, period: float = 1000.0) -> torch.Tensor:
+    """pos f32 [n] -> f32 [n, d * repeat] (PositionalEncoder)"""
+    pos = pos.reshape(-1).float().contiguous()
+    out = torch.empty((pos.numel(), d * repeat), dtype=torch.float32, device=pos.device)
+    _l.check(_l.load().ffa_positional_encoding(pos.data_ptr(), out.data_ptr(), pos.numel(), d, repeat, period,
+                                               _stream()), "positional_encoding")
+    return out
+
+
+def add_rowvec_(x: torch.Tensor, vec: torch.Tensor) -> torch.Tensor:
+    """x[n, :, :, c] += vec[n, c] in place"""
+    _chk_nhwc(x, "add_rowvec input")
+    N, H, W, C = x.shape
+    if tuple(vec.shape) != (N, C) or vec.dtype != torch.float32 or not vec.is_contiguous():
+        raise ValueError("add_rowvec: vec must be contiguous f32 [N, C]")
+    _l.check(_l.load().ffa_add_rowvec(_dt(x), x.data_ptr(), vec.data_ptr(), N, H * W, C, _stream()), "add_rowvec")
+    return x
+
+
+def ltae_attention(k: torch.Tensor, v: torch.Tensor, Q: torch.Tensor, pad: torch.Tensor, B: int, T: int):
+    """-> (out [B,h,w,n_head*d_v], attn f32 [n_head,B,T,h*w]); k / v are [B*T,h,w,n_head*d_k / n_head*d_v]"""
+    _chk_nhwc(k, "ltae keys")
+    _chk_nhwc(v, "ltae values")
+    N, h, w, KC = k.shape
+    n_head, d_k = Q.shape
+    d_v = v.shape[-1] // n_head
+    if N != B * T or KC != n_head * d_k or v.shape[:3] != k.shape[:3]:
+        raise ValueError("ltae_attention: inconsistent shapes")
+    out = torch.empty((B, h, w, n_head * d_v), dtype=v.dtype, device=v.device)
+    attn = torch.empty((n_head, B, T, h * w), dtype=torch.float32, device=v.device)
+    _l.check(_l.load().ffa_ltae_attention(_dt(v), k.data_ptr(), v.data_ptr(), Q.data_ptr(), pad.data_ptr(),
+                                          out.data_ptr(), attn.data_ptr(), B, T, h * w, n_head, d_k, d_v, _stream()),
+             "ltae_attention")
+    return out, attn
+
+
+def temporal_aggregate(x: torch.Tensor, attn: torch.Tensor, pad: torch.Tensor, B: int, T: int, use_pad: bool
+                       ) -> torch.Tensor:
+    """x [B*T,H,W,C], attn f32 [n_head,B,T,H*W] -> [B,H,W,C] (Temporal_Aggregator 'att_group')"""
+    _chk_nhwc(x, "aggregate input")
+    N, H, W, C = x.shape
+    out = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    _l.check(_l.load().ffa_temporal_aggregate(_dt(x), x.data_ptr(), attn.data_ptr(), pad.data_ptr(), out.data_ptr(), B,
+                                              T, H * W, C, attn.shape[0], 1 if use_pad else 0, _stream()),
+             "temporal_aggregate")
+    return out
+
+
+def detect_pad_images(x: torch.Tensor, value: float = 0.0) -> torch.Tensor:
+    """x f32 [N, ...] -> u8 [N]: 1 where every element of image n equals `value`"""
+    x = x.contiguous()
+    N = x.shape[0]
+    pad = torch.empty(N, dtype=torch.uint8, device=x.device)
+    _l.check(_l.load().ffa_detect_pad_images(x.data_ptr(), pad.data_ptr(), N, x.numel() // N, value, _stream()),
+             "detect_pad_images")
+    return pad
+
+
+def mask_images_(x: torch.Tensor, pad: torch.Tensor, value: float = 0.0) -> torch.Tensor:
+    N = x.shape[0]
+    _l.check(_l.load().ffa_mask_images(_dt(x), x.data_ptr(), pad.data_ptr(), N, x.numel() // N, value, _stream()),
+             "mask_images")
+    return x

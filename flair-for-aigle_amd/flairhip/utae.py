@@ -1,0 +1,256 @@
+"""U-TAE, the Sentinel time-series encoder of FLAIR-HUB, on libflairhip kernels (evaluation-mode forward).
+
+Counterpart of the reference's flair_hub/models/multitemp_model.py (UTAE :13-166, LTAE2d :169-284,
+MultiHeadAttention :316-373, ConvLayer / ConvBlock / DownConvBlock / UpConvBlock :452-599, Temporal_Aggregator
+:603-662) with the SAME parameter names, so a reference state dict loads unchanged.  Arithmetic: NHWC tensors with
+image index n = b * T + t; reflect-padded 3x3 convolutions = ffa_reflect_pad1 + ffa_conv2d(pad 0) with the bias in
+the conv epilogue; GroupNorm / attention / aggregation are the kernels of csrc/temporal.hip; evaluation-mode
+BatchNorm is folded into the packed conv operand (scale) and its bias (shift), as everywhere else in the product.
+
+Scope: the stride-1 configuration FLAIR hard-codes (flair_zonal_detection/model_utils.py:55-71:
+str_conv k=3, s=1, p=1, agg_mode 'att_group', encoder_norm 'group', padding_mode 'reflect'); evaluation mode only --
+training this branch needs the backward kernels of GroupNorm / attention / aggregation, which do not exist yet, and
+raises NotImplementedError instead of falling back to torch.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import nn as hnn
+from . import ops
+
+
+class _Affine(nn.Module):
+    """weight / bias holder (GroupNorm affine parameters)"""
+
+    def __init__(self, c: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class _Weights(nn.Module):
+    """weight / bias holder with an arbitrary weight shape (Conv2d, ConvTranspose2d, Conv1d, Linear)"""
+
+    def __init__(self, shape, n_bias: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(*shape))
+        self.bias = nn.Parameter(torch.zeros(n_bias))
+        fan_in = self.weight[0].numel()
+        nn.init.normal_(self.weight, std=(2.0 / max(fan_in, 1)) ** 0.5)
+
+
+class _Slot(nn.Module):
+    """parameter-free placeholder that keeps nn.Sequential indices aligned with the reference (its ReLU entries)"""
+
+
+def _seq(*mods) -> nn.Sequential:
+    return nn.Sequential(*mods)
+
+
+def _conv_layer(nkernels, norm: str, k: int = 3) -> nn.Module:
+    """ConvLayer (:452-497): .conv = Sequential(conv, norm, relu, conv, norm, relu, ...)"""
+    layers = []
+    for i in range(len(nkernels) - 1):
+        layers.append(_Weights((nkernels[i + 1], nkernels[i], k, k), nkernels[i + 1]))
+        layers.append(_Affine(nkernels[i + 1]) if norm == "group" else hnn.HipBatchNorm2d(nkernels[i + 1]))
+        layers.append(_Slot())
+    m = nn.Module()
+    m.conv = _seq(*layers)
+    return m
+
+
+def _block(**children) -> nn.Module:
+    m = nn.Module()
+    for k, v in children.items():
+        setattr(m, k, v)
+    return m
+
+
+class HipUTAE(nn.Module):
+    def __init__(self, input_dim: int, encoder_widths=(64, 64, 64, 128), decoder_widths=(32, 32, 64, 128),
+                 out_conv=(32, 20), str_conv_k: int = 4, str_conv_s: int = 2, str_conv_p: int = 1,
+                 agg_mode: str = "att_group", encoder_norm: str = "group", n_head: int = 16, d_model: int = 256,
+                 d_k: int = 4, encoder: bool = False, return_maps: bool = False, pad_value=0,
+                 padding_mode: str = "reflect", precision: str = "bf16"):
+        super().__init__()
+        if (str_conv_k, str_conv_s, str_conv_p) != (3, 1, 1) or agg_mode != "att_group" or encoder_norm != "group" \
+                or padding_mode != "reflect":
+            raise NotImplementedError(
+                "HipUTAE covers the configuration FLAIR hard-codes (flair_zonal_detection/model_utils.py:55-71): strided "
+                "convolutions k=3 s=1 p=1, agg_mode 'att_group', encoder_norm 'group', padding_mode 'reflect'; got "
+                f"k={str_conv_k} s={str_conv_s} p={str_conv_p} agg={agg_mode} norm={encoder_norm} pad={padding_mode}")
+        enc, dec = list(encoder_widths), list(decoder_widths if decoder_widths is not None else encoder_widths)
+        if len(enc) != len(dec) or enc[-1] != dec[-1]:
+            raise ValueError("encoder / decoder widths must have equal length and share the deepest width")
+        if d_model % n_head or enc[-1] % n_head or any(c % 16 for c in enc + dec + [d_model, n_head * d_k]):
+            raise NotImplementedError("channel widths must be multiples of 16 (and of the head count)")
+        self.n_stages, self.enc, self.dec = len(enc), enc, dec
+        self.input_dim, self.n_head, self.d_model, self.d_k = input_dim, n_head, d_model, d_k
+        self.return_maps, self.encoder, self.pad_value = return_maps or encoder, encoder, float(pad_value)
+        self.out_classes = list(out_conv)[-1]
+        self.dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+        self.in_conv = _block(conv=_conv_layer([input_dim, enc[0], enc[0]], "group"))
+        self.down_blocks = nn.ModuleList(
+            _block(down=_conv_layer([enc[i], enc[i]], "group"), conv1=_conv_layer([enc[i], enc[i + 1]], "group"),
+                   conv2=_conv_layer([enc[i + 1], enc[i + 1]], "group")) for i in range(self.n_stages - 1))
+        ups = []
+        for i in range(self.n_stages - 1, 0, -1):
+            d_in, d_out, d_skip = dec[i], dec[i - 1], enc[i - 1]
+            ups.append(_block(
+                skip_conv=_seq(_Weights((d_skip, d_skip, 1, 1), d_skip), hnn.HipBatchNorm2d(d_skip), _Slot()),
+                up=_seq(_Weights((d_in, d_out, 3, 3), d_out), hnn.HipBatchNorm2d(d_out), _Slot()),
+                conv1=_conv_layer([d_out + d_skip, d_out], "batch"), conv2=_conv_layer([d_out, d_out], "batch")))
+        self.up_blocks = nn.ModuleList(ups)
+        te = nn.Module()
+        te.inconv = _Weights((d_model, enc[-1], 1), d_model)
+        te.attention_heads = nn.Module()
+        te.attention_heads.Q = nn.Parameter(torch.randn(n_head, d_k) * (2.0 / d_k) ** 0.5)
+        te.attention_heads.fc1_k = _Weights((n_head * d_k, d_model), n_head * d_k)
+        te.in_norm, te.out_norm = _Affine(enc[-1]), _Affine(enc[-1])
+        te.mlp = _seq(_Weights((enc[-1], d_model), enc[-1]), hnn.HipBatchNorm2d(enc[-1]), _Slot())
+        self.temporal_encoder = te
+        self.out_conv = _block(conv=_conv_layer([dec[0]] + list(out_conv), "batch"))
+        self._cache = {}
+
+    # ---- operand preparation (cached per parameter version) ----------------------------------------
+
+    def _packed(self, tag: str, holder: _Weights, ci_pitch: int, bn: Optional[hnn.HipBatchNorm2d] = None,
+                transpose: bool = False, cols: Optional[slice] = None, with_bias: bool = True):
+        """(packed operand, bias vector): conv weight as 4-D OIHW (Conv1d / Linear weights are 1x1 convolutions),
+        evaluation-mode BatchNorm folded in: W' = scale * W, bias' = shift + scale * bias"""
+        ver = (holder.weight._version, holder.weight.data_ptr(), holder.bias._version, hnn.state_epoch(),
+               None if bn is None else (bn.weight._version, bn.bias._version, bn.running_mean._version,
+                                        bn.running_var._version, getattr(bn, "_stats_epoch", 0)), self.dtype)
+        hit = self._cache.get(tag)
+        if hit is not None and hit[0] == ver:
+            return hit[1], hit[2]
+        w = holder.weight.detach().float()
+        if w.dim() == 3:
+            w = w.unsqueeze(-1)
+        elif w.dim() == 2:
+            w = w[:, :, None, None]
+        if cols is not None:
+            w = w[:, cols]
+        w = w.contiguous()
+        n_out = w.shape[1] if transpose else w.shape[0]
+        scale = shift = None
+        if bn is not None:
+            scale, shift = ops.bn_eval_params(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                              bn.eps)
+        pw = ops.pack_conv_weight(w, self.dtype, 1, ci_pitch, transpose=transpose, scale=scale, allow_ring=False)
+        out_pitch = ops.pad_channels(n_out) if n_out != self.out_classes else hnn.LOGIT_PITCH
+        bias = torch.zeros(max(out_pitch, pw.rows), dtype=torch.float32, device=w.device)
+        if with_bias:
+            b = holder.bias.detach().float()
+            bias[:n_out] = b if scale is None else shift[:n_out] + scale[:n_out] * b
+        elif scale is not None:
+            raise ValueError("a folded BatchNorm needs its shift in the bias vector")
+        self._cache[tag] = (ver, pw, bias)
+        return pw, bias
+
+    def _conv_gn(self, x, seq, idx: int, tag: str, relu=True, residual=None):
+        """reflect-pad conv3x3 + bias -> GroupNorm(4) -> ReLU (-> + residual): ConvLayer with norm='group'"""
+        conv, gn = seq[idx], seq[idx + 1]
+        pw, bias = self._packed(tag, conv, x.shape[-1])
+        y = ops.conv2d(ops.reflect_pad1(x), pw, 0, ops.pad_channels(conv.weight.shape[0]), bias=bias)
+        return ops.group_norm(y, gn.weight.detach().float(), gn.bias.detach().float(), 4, relu=relu, residual=residual)
+
+    def _conv_bn(self, x, seq, idx: int, tag: str):
+        """reflect-pad conv3x3 + bias -> BatchNorm (eval, folded) -> ReLU: ConvLayer with norm='batch'"""
+        conv, bn = seq[idx], seq[idx + 1]
+        pw, bias = self._packed(tag, conv, x.shape[-1], bn=bn)
+        n_out = conv.weight.shape[0]
+        pitch = ops.pad_channels(n_out) if n_out != self.out_classes else hnn.LOGIT_PITCH
+        return ops.conv2d(ops.reflect_pad1(x), pw, 0, pitch, bias=bias, relu=True)
+
+    # ---- forward -------------------------------------------------------------------------------------
+
+    def forward_nhwc(self, x: torch.Tensor, batch_positions: torch.Tensor):
+        """x f32 [B,T,C,H,W], batch_positions [B,T] -> (logits NHWC [B,H,W,pitch], maps NHWC (coarse to fine),
+        attn f32 [n_head,B,T,H,W])"""
+        if self.training:
+            raise NotImplementedError("HipUTAE: evaluation-mode forward only (no backward kernels for GroupNorm / "
+                                      "L-TAE attention / temporal aggregation yet); call .eval()")
+        if not x.is_cuda:
+            raise RuntimeError("HipUTAE runs on the MI355X only (no CPU path in the product)")
+        B, T, C, H, W = x.shape
+        if C != self.input_dim or H < 2 or W < 2:
+            raise ValueError(f"expected [B,T,{self.input_dim},H>=2,W>=2], got {tuple(x.shape)}")
+        N = B * T
+        flat = x.reshape(N, C, H, W).float().contiguous()
+        pad = ops.detect_pad_images(flat, self.pad_value)            # u8 [N], n = b * T + t
+        any_pad = bool(pad.any())                                    # Temporal_Aggregator branches on it (:609)
+        cur = ops.nchw_to_nhwc(flat, self.dtype, ops.pad_channels(C))
+
+        def shared(t):  # TemporallySharedBlock.smart_forward: padded dates come out as pad_value
+            return ops.mask_images_(t, pad, self.pad_value)
+
+        seq = self.in_conv.conv.conv
+        cur = shared(self._conv_gn(self._conv_gn(cur, seq, 0, "in0"), seq, 3, "in1"))
+        fmaps: List[torch.Tensor] = [cur]
+        for i, blk in enumerate(self.down_blocks):
+            t = self._conv_gn(fmaps[-1], blk.down.conv, 0, f"d{i}a")
+            t = self._conv_gn(t, blk.conv1.conv, 0, f"d{i}b")
+            t = self._conv_gn(t, blk.conv2.conv, 0, f"d{i}c", residual=t)  # out + conv2(out)
+            fmaps.append(shared(t))
+
+        # ---- L-TAE (:237-284) ----
+        te = self.temporal_encoder
+        z = ops.group_norm_seq(fmaps[-1], B, T, te.in_norm.weight.detach().float(), te.in_norm.bias.detach().float(),
+                               self.n_head)
+        pw, bias = self._packed("inconv", te.inconv, z.shape[-1])
+        z = ops.conv2d(z, pw, 0, self.d_model, bias=bias)
+        pe = ops.positional_encoding(batch_positions.to(x.device), self.d_model // self.n_head, self.n_head)
+        ops.add_rowvec_(z, pe)
+        pw, bias = self._packed("fc1_k", te.attention_heads.fc1_k, self.d_model)
+        keys = ops.conv2d(z, pw, 0, self.n_head * self.d_k, bias=bias)
+        o, attn = ops.ltae_attention(keys, z, te.attention_heads.Q.detach().float().contiguous(), pad, B, T)
+        pw, bias = self._packed("mlp", te.mlp[0], self.d_model, bn=te.mlp[1])
+        o = ops.conv2d(o, pw, 0, self.enc[-1], bias=bias, relu=True)
+        out = ops.group_norm_seq(o, B, 1, te.out_norm.weight.detach().float(), te.out_norm.bias.detach().float(),
+                                 self.n_head)
+
+        # ---- decoder (:150-157, UpConvBlock :568-599) ----
+        maps = [out]
+        for i, blk in enumerate(self.up_blocks):
+            skip_src = fmaps[-(i + 2)]
+            if skip_src.shape[1:3] != fmaps[-1].shape[1:3]:
+                raise NotImplementedError("attention masks are used at their own resolution (stride-1 U-TAE)")
+            skip = ops.temporal_aggregate(skip_src, attn, pad, B, T, any_pad)
+            pw, bias = self._packed(f"u{i}up", blk.up[0], out.shape[-1], bn=blk.up[1], transpose=True)
+            d_out = blk.up[0].weight.shape[1]
+            up = ops.conv2d(out, pw, 1, ops.pad_channels(d_out), bias=bias, relu=True)  # ConvTranspose2d(3,1,1)
+            pw, bias = self._packed(f"u{i}skip", blk.skip_conv[0], skip.shape[-1], bn=blk.skip_conv[1])
+            sk = ops.conv2d(skip, pw, 0, skip.shape[-1], bias=bias, relu=True)
+            # conv1 over cat([up, sk]) without the concat: one convolution per source, chained through the residual
+            c1, bn1 = blk.conv1.conv[0], blk.conv1.conv[1]
+            pa, bias = self._packed(f"u{i}c1a", c1, up.shape[-1], bn=bn1, cols=slice(0, d_out))
+            pb, _ = self._packed(f"u{i}c1b", c1, sk.shape[-1], bn=bn1, cols=slice(d_out, None))
+            t = ops.conv2d(ops.reflect_pad1(up), pa, 0, ops.pad_channels(d_out), bias=bias)
+            y = ops.conv2d(ops.reflect_pad1(sk), pb, 0, ops.pad_channels(d_out), residual=t, relu=True)
+            y2 = self._conv_bn(y, blk.conv2.conv, 0, f"u{i}c2")
+            one = torch.ones(y.shape[-1], dtype=torch.float32, device=y.device)
+            out = ops.bn_apply(y2, one, torch.zeros_like(one), residual=y, relu=False)  # out + conv2(out)
+            maps.append(out)
+        seq = self.out_conv.conv.conv
+        logits = self._conv_bn(self._conv_bn(out, seq, 0, "o0"), seq, 3, "o1")
+        return logits, maps, attn.view(self.n_head, B, T, H, W)
+
+    def forward(self, input: torch.Tensor, batch_positions: Optional[torch.Tensor] = None, return_att: bool = False):
+        """the reference's return convention (:158-166), NCHW float32 tensors"""
+        logits, maps, attn = self.forward_nhwc(input, batch_positions)
+        to_nchw = lambda t, c: ops.nhwc_to_nchw(t, c)
+        widths = [self.dec[-1]] + [self.dec[i - 1] for i in range(self.n_stages - 1, 0, -1)]
+        maps_nchw = [to_nchw(m, c) for m, c in zip(maps, widths)]
+        if self.encoder:
+            return maps_nchw[-1], maps_nchw
+        out = to_nchw(logits, self.out_classes)
+        if return_att:
+            return out, attn
+        if self.return_maps:
+            return out, maps_nchw
+        return out

@@ -136,6 +136,37 @@ int ffa_conv_wgrad_upcat(int dtype, const void* lo, const void* skip, const void
                          int Wl, int C1, int C2, int Co, int Co_real, int accumulate, void* workspace,
                          long long workspace_bytes, ffa_stream_t stream);
 
+/* ---- U-TAE Sentinel time-series branch (flair_hub/models/multitemp_model.py) ------------------
+ * Small NHWC kernels around ffa_conv2d for the temporally shared encoder, the L-TAE and the attention-weighted skip
+ * aggregation; evaluation-mode forward. */
+/* out[n][y][x] = in[n][refl(y-1)][refl(x-1)]: the padding of nn.Conv2d(padding=1, padding_mode="reflect")
+ * (multitemp_model.py:473-482); the convolution itself is ffa_conv2d with pad 0 on the padded tensor */
+int ffa_reflect_pad1(int dtype, const void* in, void* out, int N, int H, int W, int C, ffa_stream_t stream);
+/* y = [residual +] relu?(GroupNorm(x)): nn.GroupNorm of ConvLayer (:464-468, 4 groups over an image) and of LTAE2d
+ * (:224-231, 16 groups over the dates of one pixel).  Sample s starts at element (s / Q) * stride_hi +
+ * (s % Q) * stride_lo and has `inner` positions, inner_stride elements apart, of C contiguous channels. */
+int ffa_group_norm(int dtype, const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                   long long samples, int Q, long long stride_hi, long long stride_lo, int inner,
+                   long long inner_stride, int C, int groups, float eps, int relu, ffa_stream_t stream);
+/* PositionalEncoder (:287-313): out[n][r*d + j] = sin|cos(pos[n] / period^(2*(j/2)/d)), repeated `repeat` times */
+int ffa_positional_encoding(const float* pos, float* out, int n, int d, int repeat, float period, ffa_stream_t stream);
+/* x[n][p][c] += vec[n][c] (f32 vec): "out + positional_encoder(bp)" (:270) */
+int ffa_add_rowvec(int dtype, void* x, const float* vec, int N, int P, int C, ffa_stream_t stream);
+/* MultiHeadAttention with one learnt query per head + masked softmax over the dates (:337-403), per pixel:
+ * k [B][T][P][n_head*d_k], v [B][T][P][n_head*d_v], Q f32 [n_head][d_k], pad u8 [B][T] ->
+ * out [B][P][n_head*d_v], attn f32 [n_head][B][T][P] */
+int ffa_ltae_attention(int dtype, const void* k, const void* v, const float* Q, const unsigned char* pad, void* out,
+                       float* attn, int B, int T, int P, int n_head, int d_k, int d_v, ffa_stream_t stream);
+/* Temporal_Aggregator(mode="att_group") (:609-628,640-654): out[b][p][c] = sum_t attn[c/(C/n_head)][b][t][p] *
+ * x[b][t][p][c], padded dates dropped when use_pad; attn already at the resolution of x */
+int ffa_temporal_aggregate(int dtype, const void* x, const float* attn, const unsigned char* pad, void* out, int B,
+                           int T, int P, int C, int n_head, int use_pad, ffa_stream_t stream);
+/* TemporallySharedBlock.smart_forward (:420-447): pad[n] = image n is all `value`; padded images come out as `value` */
+int ffa_detect_pad_images(const float* x, unsigned char* pad, int N, long long per_image, float value,
+                          ffa_stream_t stream);
+int ffa_mask_images(int dtype, void* x, const unsigned char* pad, int N, long long per_image, float value,
+                    ffa_stream_t stream);
+
 /* ---- BatchNorm2d + ReLU + residual, MaxPool2d(3,2,1) (smp ResNet-34 encoder / UnetDecoder blocks;
  *      SURVEY.md Appendix C) ----------------------------------------------------------------------- */
 long long ffa_bn_workspace_bytes(int C);

@@ -385,3 +385,64 @@ def test_nearest_zoom_index_equals_scipy():
             assert got.shape == ref.shape and np.array_equal(got, ref), (n, z)
             hit_constant += int((ref == 0).any())
     assert hit_constant > 0  # the quirk is exercised
+
+
+def test_utae_oracle_matches_the_references_own_utae():
+    """oracle/utae.py (functional CPU restatement) against the outputs of the reference's UTAE class itself on the
+    same seeded weights: logits, every decoder feature map and the attention masks, without and with padded dates."""
+    import sys
+    import types
+    from oracle.seeded_weights import fill_utae_state_dict
+    from oracle.utae import utae_forward
+    d = np.load(os.path.join(GOLD, "utae_eval.npz"))
+    shapes = _utae_state_shapes()
+    sd = fill_utae_state_dict({k: torch.zeros(s) for k, s in shapes.items()})
+    for tag in ("a", "b"):
+        x, pos = torch.tensor(d[f"{tag}_x"]), torch.tensor(d[f"{tag}_pos"])
+        logits, maps, att = utae_forward(sd, x, pos)
+        assert np.abs(logits.numpy() - d[f"{tag}_logits"]).max() <= 2e-5
+        assert np.abs(att.numpy() - d[f"{tag}_att"]).max() <= 1e-6
+        for i, m in enumerate(maps):
+            assert np.abs(m.numpy() - d[f"{tag}_map{i}"]).max() <= 2e-5, i
+
+
+def _utae_state_shapes(input_dim=10, enc=(64, 64, 64, 128), dec=(32, 32, 64, 128), out_conv=(32, 19), n_head=16,
+                       d_model=256, d_k=4):
+    """parameter / buffer names and shapes of the reference's UTAE (multitemp_model.py:73-130), spelled out so that the
+    tests need no reference import"""
+    s = {}
+
+    def conv(pre, ci, co, k=3):
+        s[pre + ".weight"], s[pre + ".bias"] = (co, ci, k, k), (co,)
+
+    def gn(pre, c):
+        s[pre + ".weight"], s[pre + ".bias"] = (c,), (c,)
+
+    def bn(pre, c):
+        gn(pre, c)
+        s[pre + ".running_mean"], s[pre + ".running_var"], s[pre + ".num_batches_tracked"] = (c,), (c,), ()
+
+    conv("in_conv.conv.conv.0", input_dim, enc[0]); gn("in_conv.conv.conv.1", enc[0])
+    conv("in_conv.conv.conv.3", enc[0], enc[0]); gn("in_conv.conv.conv.4", enc[0])
+    for i in range(len(enc) - 1):
+        conv(f"down_blocks.{i}.down.conv.0", enc[i], enc[i]); gn(f"down_blocks.{i}.down.conv.1", enc[i])
+        conv(f"down_blocks.{i}.conv1.conv.0", enc[i], enc[i + 1]); gn(f"down_blocks.{i}.conv1.conv.1", enc[i + 1])
+        conv(f"down_blocks.{i}.conv2.conv.0", enc[i + 1], enc[i + 1]); gn(f"down_blocks.{i}.conv2.conv.1", enc[i + 1])
+    for j, i in enumerate(range(len(enc) - 1, 0, -1)):
+        d_in, d_out, d_skip = dec[i], dec[i - 1], enc[i - 1]
+        pre = f"up_blocks.{j}"
+        conv(pre + ".skip_conv.0", d_skip, d_skip, 1); bn(pre + ".skip_conv.1", d_skip)
+        s[pre + ".up.0.weight"], s[pre + ".up.0.bias"] = (d_in, d_out, 3, 3), (d_out,)
+        bn(pre + ".up.1", d_out)
+        conv(pre + ".conv1.conv.0", d_out + d_skip, d_out); bn(pre + ".conv1.conv.1", d_out)
+        conv(pre + ".conv2.conv.0", d_out, d_out); bn(pre + ".conv2.conv.1", d_out)
+    t = "temporal_encoder"
+    s[t + ".inconv.weight"], s[t + ".inconv.bias"] = (d_model, enc[-1], 1), (d_model,)
+    s[t + ".attention_heads.Q"] = (n_head, d_k)
+    s[t + ".attention_heads.fc1_k.weight"], s[t + ".attention_heads.fc1_k.bias"] = (n_head * d_k, d_model), (n_head * d_k,)
+    gn(t + ".in_norm", enc[-1]); gn(t + ".out_norm", enc[-1])
+    s[t + ".mlp.0.weight"], s[t + ".mlp.0.bias"] = (enc[-1], d_model), (enc[-1],)
+    bn(t + ".mlp.1", enc[-1])
+    conv("out_conv.conv.conv.0", dec[0], out_conv[0]); bn("out_conv.conv.conv.1", out_conv[0])
+    conv("out_conv.conv.conv.3", out_conv[0], out_conv[1]); bn("out_conv.conv.conv.4", out_conv[1])
+    return s
