@@ -72,10 +72,11 @@ class FusionHandler(nn.Module):
             return feature_maps[mono[0]]
         if not mono and len(multi) == 1:
             return feature_maps[multi[0]]
-        if multi:
-            raise NotImplementedError(
-                f"feature fusion with Sentinel time-series branches {multi} is not implemented on libflairhip yet "
-                "(SURVEY.md section 8f rank 3)")
+        if not mono:
+            raise NotImplementedError(f"averaging the class scores of several Sentinel branches {multi} (reference "
+                                      ":497-502) is not built; use one time-series modality or add an aerial one")
+        # case 4 (:504-547): a U-TAE branch contributes its decoder maps, coarse to fine, one per aerial stage (the
+        # reference zips them in list order, flair_model.py:514-531); every map is resized to the stage it meets
         nstage = len(target_fm_maps)
         fused = [target_fm_maps[0]]
         for s in range(1, nstage):
@@ -112,38 +113,65 @@ class FLAIR_HUB_Model(nn.Module):
             pp = mods["pre_processings"]
             self.channels_dict["DEM_ELEV"] = 1 if (pp["calc_elevation"] and not pp["calc_elevation_stack_dsm"]) else 2
 
-        if any(inputs.get(k, False) for k in self.multi_keys):
-            raise NotImplementedError("Sentinel time-series (U-TAE) branch is not implemented on libflairhip yet "
-                                      "(SURVEY.md section 8f rank 3)")
-        for m in self.aux_losses:
-            if m not in self.mono_keys:
-                raise NotImplementedError(f"auxiliary decoder for '{m}' needs the U-TAE branch (SURVEY.md 8f rank 3)")
-
         self.encoders = nn.ModuleDict()
         for m in self.mono_keys:
             if inputs.get(m, False):
                 self.encoders[m] = FLAIR_Monotemp(config, channels=self.channels_dict[m], classes=self.task_nclasses,
                                                   img_size=img_input_sizes[m], return_type="encoder")
+        has_mono = len(self.encoders) > 0
+
+        # Sentinel time-series branches (reference :101-134): U-TAE with FLAIR's fixed hyper-parameters; its class
+        # score layer covers all tasks, and next to aerial encoders its widths follow their stage count
+        active_multi = [k for k in self.multi_keys if inputs.get(k, False)]
+        if active_multi:
+            mt = config["models"]["multitemp_model"]
+            if self.task_nclasses != mt["out_conv"][-1]:
+                mt["out_conv"].append(self.task_nclasses)
+            if has_mono:
+                mono_ch = next(iter(self.encoders.values())).seg_model.out_channels
+                mt["encoder_widths"] = self.adjust_fm_length(config, mono_ch)
+                mt["decoder_widths"] = self.adjust_fm_length(config, mono_ch)
+            from flairhip.utae import HipUTAE
+            for m in active_multi:
+                self.encoders[m] = HipUTAE(
+                    input_dim=len(mods["inputs_channels"][m]), encoder_widths=mt["encoder_widths"],
+                    decoder_widths=mt["decoder_widths"], out_conv=mt["out_conv"], str_conv_k=mt["str_conv_k"],
+                    str_conv_s=mt["str_conv_s"], str_conv_p=mt["str_conv_p"], agg_mode=mt["agg_mode"],
+                    encoder_norm=mt["encoder_norm"], n_head=mt["n_head"], d_model=mt["d_model"], d_k=mt["d_k"],
+                    encoder=False, return_maps=True, pad_value=mt["pad_value"], padding_mode=mt["padding_mode"],
+                    precision="bf16" if self.compute_dtype == torch.bfloat16 else "fp32")
         if not self.encoders:
             raise ValueError("no active input modality in config['modalities']['inputs']")
 
-        per_stage = [list(self.encoders[m].seg_model.out_channels) for m in self.encoders]
-        total_per_stage = [sum(c) for c in zip(*per_stage)]
-        target = next(iter(self.encoders.values())).seg_model.out_channels
+        def n_cls(task):
+            return len(config["labels_configs"][task]["value_name"])
+
+        if has_mono:
+            # channels per stage of every modality (reference calc_backbones_channels :290-314): the aerial stages, and
+            # for a U-TAE branch its decoder widths reversed (its maps come coarse to fine)
+            stage_channels = {m: list(self.encoders[m].seg_model.out_channels) for m in self.encoders
+                              if m in self.mono_keys}
+            for m in active_multi:
+                stage_channels[m] = list(config["models"]["multitemp_model"]["decoder_widths"])[::-1]
+            total_per_stage = [sum(c) for c in zip(*stage_channels.values())]
+            target = next(iter(self.encoders.values())).seg_model.out_channels
+        else:
+            stage_channels, total_per_stage, target = {}, [1], [1]  # the reference's dummy (:141-143)
         self.fusion_handler = FusionHandler(total_per_stage, target, self.mono_keys, self.multi_keys)
-        self.fusion_handler.stage_channels = {m: list(self.encoders[m].seg_model.out_channels) for m in self.encoders}
+        self.fusion_handler.stage_channels = stage_channels
 
         self.main_decoders = nn.ModuleDict()
         for task in config["labels"]:
-            self.main_decoders[task] = FLAIR_Monotemp(
-                config, channels=1, classes=len(config["labels_configs"][task]["value_name"]), return_type="decoder")
+            # U-Net decoders over the fused aerial stages, or -- Sentinel only -- a 1x1 head over the U-TAE scores
+            self.main_decoders[task] = FLAIR_Monotemp(config, channels=1, classes=n_cls(task), return_type="decoder") \
+                if has_mono else hnn.HipConv2d(self.task_nclasses, n_cls(task), 1, 1, 0, bias=True)
         # one extra decoder per (aux-loss modality, task), fed by that modality's own features (reference :170-188)
         self.aux_decoders = nn.ModuleDict()
         for task in config["labels"]:
             for m in self.aux_losses:
                 self.aux_decoders[f"{m}__{task}"] = FLAIR_Monotemp(
-                    config, channels=1, classes=len(config["labels_configs"][task]["value_name"]),
-                    return_type="decoder")
+                    config, channels=1, classes=n_cls(task), return_type="decoder") if m in self.mono_keys \
+                    else hnn.HipConv2d(self.task_nclasses, n_cls(task), 1, 1, 0, bias=True)
         self._pack_plan = hnn.PackPlan(self)
         self._log_parameter_table()
 
@@ -159,6 +187,19 @@ class FLAIR_HUB_Model(nn.Module):
                 total += n
                 logger.info("| %-30s | %-28s | %-14s | %13s |", key, arch, kind, f"{n:,}")
         logger.info("| %-30s   %-28s   %-14s   %13s |", "Total parameters", "", "", f"{total:,}")
+
+    @staticmethod
+    def adjust_fm_length(config: dict, mono_temp_backbone_channels) -> List[int]:
+        """U-TAE widths next to an aerial encoder (reference :196-214): as many stages as the encoder has (without
+        its two zero-channel dummies), linearly spaced between the configured extremes and snapped to powers of two
+        -- [64, 64, 64, 128] becomes [64, 64, 64, 128, 128, 128] for the six ResNet-34 stages"""
+        import numpy as np
+        ch = list(mono_temp_backbone_channels)
+        if len(ch) > 2 and (ch[0] == 0 or ch[1] == 0):
+            ch = ch[2:]
+        widths = config["models"]["multitemp_model"]["encoder_widths"]
+        spaced = np.linspace(min(widths) - 1, max(widths) + 1, len(ch)).astype(int)
+        return [int(2 ** round(math.log(int(v), 2))) for v in spaced]
 
     def interpolate_map(self, x: torch.Tensor, size) -> torch.Tensor:
         """bilinear, align_corners=False (reference :318-327); ``size`` may be an int as in the reference's call."""
@@ -232,16 +273,44 @@ class FLAIR_HUB_Model(nn.Module):
             y = self.interpolate_map(decoder.seg_model(*feats), img_size)
             return hnn.logits_view(y, len(self.config["labels_configs"][task]["value_name"]))
 
+        def head1x1(conv, scores, task):  # the Sentinel-only model's nn.Conv2d(task_nclasses, classes, 1) (:153-166)
+            pw = conv.packed(scores.dtype, ring=False)
+            bias = torch.zeros(conv.out_pitch, dtype=torch.float32, device=scores.device)
+            bias[: conv.out_channels] = conv.bias.detach()
+            y = ops.conv2d(scores, pw, 0, conv.out_pitch, bias=bias)
+            return hnn.logits_view(y, len(self.config["labels_configs"][task]["value_name"]))
+
+        scores: Dict[str, torch.Tensor] = {}  # class scores of the time-series branches (NHWC)
         for mod, encoder in self.encoders.items():
-            fmaps[mod] = encoder.seg_model(self._input_nhwc(batch[mod], mod, batch.get(mod + "_NORM")))
-            if self.aux_losses.get(mod):
-                for task in labels:
-                    logits_aux[f"aux_{mod}_{task}"] = decode(self.aux_decoders[f"{mod}__{task}"], fmaps[mod], task)
+            if mod in self.mono_keys:
+                fmaps[mod] = encoder.seg_model(self._input_nhwc(batch[mod], mod, batch.get(mod + "_NORM")))
+                if self.aux_losses.get(mod):
+                    for task in labels:
+                        logits_aux[f"aux_{mod}_{task}"] = decode(self.aux_decoders[f"{mod}__{task}"], fmaps[mod], task)
+            else:
+                # U-TAE: class scores AND decoder maps (reference :388-404); dates ride along as '<SENSOR>_DATES'
+                dates = batch.get(mod.replace("TS", "DATES"))
+                if dates is None:
+                    raise KeyError(f"batch['{mod.replace('TS', 'DATES')}'] (acquisition dates, [B, T]) is required")
+                s_nhwc, maps, _ = encoder.forward_nhwc(batch[mod], dates)
+                scores[mod] = self.interpolate_map(s_nhwc, img_size)
+                fmaps[mod] = maps
+                if self.aux_losses.get(mod):
+                    for task in labels:
+                        logits_aux[f"aux_{mod}_{task}"] = head1x1(self.aux_decoders[f"{mod}__{task}"], scores[mod], task)
 
         if apply_mod_dropout and len(self.encoders) > 1:
             fmaps = self.modality_dropout(fmaps, {key: random.uniform(0, 1) for key in fmaps.keys()})
 
-        fused = self.fusion_handler(fmaps, fmaps[first_mod])
-        for task in labels:
-            logits_tasks[task] = decode(self.main_decoders[task], fused, task)
+        if any(m in self.mono_keys for m in self.encoders):
+            fused = self.fusion_handler(fmaps, fmaps[first_mod])
+            for task in labels:
+                logits_tasks[task] = decode(self.main_decoders[task], fused, task)
+        else:
+            fused_scores = self.fusion_handler(scores, None)  # one time-series branch: its scores (:493-494)
+            for task in labels:
+                if len(labels) > 1:
+                    logits_tasks[task] = head1x1(self.main_decoders[task], fused_scores, task)
+                else:
+                    logits_tasks[task] = hnn.logits_view(fused_scores, self.task_nclasses)
         return logits_tasks, logits_aux

@@ -142,7 +142,7 @@ class HipUTAE(nn.Module):
             scale, shift = ops.bn_eval_params(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                               bn.eps)
         pw = ops.pack_conv_weight(w, self.dtype, 1, ci_pitch, transpose=transpose, scale=scale, allow_ring=False)
-        out_pitch = ops.pad_channels(n_out) if n_out != self.out_classes else hnn.LOGIT_PITCH
+        out_pitch = self._pitch(n_out)
         bias = torch.zeros(max(out_pitch, pw.rows), dtype=torch.float32, device=w.device)
         if with_bias:
             b = holder.bias.detach().float()
@@ -151,6 +151,11 @@ class HipUTAE(nn.Module):
             raise ValueError("a folded BatchNorm needs its shift in the bias vector")
         self._cache[tag] = (ver, pw, bias)
         return pw, bias
+
+    def _pitch(self, n: int) -> int:
+        """stored channel pitch of an n-channel tensor: class-score tensors of up to LOGIT_PITCH classes use the
+        product's logits pitch (what the loss / argmax kernels expect), everything else the next multiple of 16"""
+        return hnn.LOGIT_PITCH if (n == self.out_classes and n <= hnn.LOGIT_PITCH) else ops.pad_channels(n)
 
     def _conv_gn(self, x, seq, idx: int, tag: str, relu=True, residual=None):
         """reflect-pad conv3x3 + bias -> GroupNorm(4) -> ReLU (-> + residual): ConvLayer with norm='group'"""
@@ -163,9 +168,7 @@ class HipUTAE(nn.Module):
         """reflect-pad conv3x3 + bias -> BatchNorm (eval, folded) -> ReLU: ConvLayer with norm='batch'"""
         conv, bn = seq[idx], seq[idx + 1]
         pw, bias = self._packed(tag, conv, x.shape[-1], bn=bn)
-        n_out = conv.weight.shape[0]
-        pitch = ops.pad_channels(n_out) if n_out != self.out_classes else hnn.LOGIT_PITCH
-        return ops.conv2d(ops.reflect_pad1(x), pw, 0, pitch, bias=bias, relu=True)
+        return ops.conv2d(ops.reflect_pad1(x), pw, 0, self._pitch(conv.weight.shape[0]), bias=bias, relu=True)
 
     # ---- forward -------------------------------------------------------------------------------------
 
@@ -236,8 +239,10 @@ class HipUTAE(nn.Module):
             one = torch.ones(y.shape[-1], dtype=torch.float32, device=y.device)
             out = ops.bn_apply(y2, one, torch.zeros_like(one), residual=y, relu=False)  # out + conv2(out)
             maps.append(out)
-        seq = self.out_conv.conv.conv
-        logits = self._conv_bn(self._conv_bn(out, seq, 0, "o0"), seq, 3, "o1")
+        seq = self.out_conv.conv.conv  # ConvBlock([dec[0]] + out_conv): conv -> BN -> ReLU per entry of out_conv
+        logits = out
+        for j in range(len(seq) // 3):
+            logits = self._conv_bn(logits, seq, 3 * j, f"o{j}")
         return logits, maps, attn.view(self.n_head, B, T, H, W)
 
     def forward(self, input: torch.Tensor, batch_positions: Optional[torch.Tensor] = None, return_att: bool = False):

@@ -14,7 +14,7 @@ small stand-in modules injected into sys.modules for those imports ONLY inside t
 Only data (inputs + the reference's outputs) is written; no reference source is copied.  The fixtures are
 committed; this script is not run on the GPU box (the reference does not travel).
 
-Usage:  python tests/golden/gen_goldens.py [fusion]
+Usage:  python tests/golden/gen_goldens.py [fusion | sentinel]
 """
 from __future__ import annotations
 
@@ -389,8 +389,79 @@ def gen_fusion(path_json, path_npz):
           f"{len(info['unused_parameters'])} parameters without gradient")
 
 
+def _fill_mixed(sd):
+    """seeded weights: the U-TAE rules for the Sentinel encoder's tensors, the U-Net rules for everything else"""
+    from oracle.seeded_weights import fill_state_dict, fill_utae_state_dict
+    utae = {k: v for k, v in sd.items() if k.startswith("encoders.SENTINEL")}
+    rest = {k: v for k, v in sd.items() if k not in utae}
+    out = fill_state_dict(rest) if rest else {}
+    out.update(fill_utae_state_dict(utae))
+    # 1x1 task heads of the Sentinel-only model (nn.Conv2d weights are 4-D: fill_state_dict handles them)
+    return out
+
+
+def gen_sentinel(path_json, path_npz):
+    """The reference's FLAIR_HUB_Model with a Sentinel-2 time-series branch, evaluation-mode forward on CPU:
+      s1: SENTINEL2_TS only, two tasks (COSIA 19 + LPIS 23 classes -> U-TAE out_conv grows to 42, one 1x1 head per
+          task: flair_model.py:101-104,153-166,420-424), one padded date
+      s2: AERIAL_RGBI (64 x 64 x 5) + SENTINEL2_TS (10 x 10 x 10, T = 4), one task: U-TAE widths adjusted to the six
+          aerial stages (:106-112,196-214), FusionHandler case 4 (:504-547)"""
+    from flair_hub.tasks.module_setup import build_segmentation_module
+    cfgs = _load_cfgs()
+    g = torch.Generator().manual_seed(31)
+    out, info = {}, {}
+    # ---- s1 ----
+    cfg = cfgs.fusion_unet_config(precision="fp32", aux_loss=False)
+    cfg["modalities"]["inputs"] = {m: (m == "SENTINEL2_TS") for m in cfg["modalities"]["inputs"]}
+    cfg["modalities"]["inputs_channels"]["SENTINEL2_TS"] = list(range(1, 11))
+    cfg["modalities"]["aux_loss"] = {m: False for m in cfg["modalities"]["aux_loss"]}
+    torch.manual_seed(2025)
+    task = build_segmentation_module(cfg, {"SENTINEL2_TS": 10}, stage="train")
+    task.model.load_state_dict(_fill_mixed(task.model.state_dict()))
+    xs = torch.randn(2, 5, 10, 10, 10, generator=g)
+    xs[1, 4] = 0.0
+    pos = torch.sort(torch.randint(0, 365, (2, 5), generator=g), dim=1).values.float()
+    batch = {"SENTINEL2_TS": xs, "SENTINEL2_DATES": pos, "AERIAL_LABEL-COSIA": torch.zeros(2, 19, 40, 40),
+             "ALL_LABEL-LPIS": torch.zeros(2, 40, 40, dtype=torch.long)}
+    task.eval()
+    with torch.no_grad():
+        lt, la = task.model(batch)
+    out.update(s1_x=xs.numpy(), s1_pos=pos.numpy(), s1_logits_cosia=lt["AERIAL_LABEL-COSIA"].numpy(),
+               s1_logits_lpis=lt["ALL_LABEL-LPIS"].numpy())
+    info["s1"] = {"logit_keys": sorted(lt.keys()), "aux_keys": sorted(la.keys()),
+                  "state_dict_keys": sorted(task.model.state_dict().keys()),
+                  "multitemp_model": {k: cfg["models"]["multitemp_model"][k] for k in ("encoder_widths", "decoder_widths", "out_conv")}}
+    print("  sentinel s1:", {k: tuple(v.shape) for k, v in lt.items()}, info["s1"]["multitemp_model"])
+    # ---- s2 ----
+    cfg = cfgs.unet_resnet34_config(in_channels=5, precision="fp32")
+    cfg["modalities"]["inputs"]["SENTINEL2_TS"] = True
+    cfg["modalities"]["inputs_channels"]["SENTINEL2_TS"] = list(range(1, 11))
+    torch.manual_seed(2025)
+    task = build_segmentation_module(cfg, {"AERIAL_RGBI": 64, "SENTINEL2_TS": 10}, stage="train")
+    task.model.load_state_dict(_fill_mixed(task.model.state_dict()))
+    xa = torch.randn(2, 5, 64, 64, generator=g)
+    xs = torch.randn(2, 4, 10, 10, 10, generator=g)
+    pos = torch.sort(torch.randint(0, 365, (2, 4), generator=g), dim=1).values.float()
+    batch = {"AERIAL_RGBI": xa, "SENTINEL2_TS": xs, "SENTINEL2_DATES": pos,
+             "AERIAL_LABEL-COSIA": torch.zeros(2, 19, 64, 64)}
+    task.eval()
+    with torch.no_grad():
+        lt, la = task.model(batch)
+    out.update(s2_x_aerial=xa.numpy(), s2_x=xs.numpy(), s2_pos=pos.numpy(), s2_logits=lt["AERIAL_LABEL-COSIA"].numpy())
+    info["s2"] = {"logit_keys": sorted(lt.keys()), "aux_keys": sorted(la.keys()),
+                  "state_dict_keys": sorted(task.model.state_dict().keys()),
+                  "state_dict_shapes": {k: list(v.shape) for k, v in task.model.state_dict().items()
+                                        if k.startswith(("encoders.SENTINEL2_TS", "fusion_handler"))},
+                  "multitemp_model": {k: cfg["models"]["multitemp_model"][k] for k in ("encoder_widths", "decoder_widths", "out_conv")}}
+    print("  sentinel s2:", {k: tuple(v.shape) for k, v in lt.items()}, info["s2"]["multitemp_model"])
+    np.savez_compressed(path_npz, **out)
+    json.dump(info, open(path_json, "w"), indent=1)
+
+
 def main():
     install_stubs()
+    if sys.argv[1:] == ["sentinel"]:
+        return gen_sentinel(os.path.join(HERE, "sentinel.json"), os.path.join(HERE, "sentinel.npz"))
     if sys.argv[1:] == ["fusion"]:  # regenerate only the multi-modality fixture
         return gen_fusion(os.path.join(HERE, "fusion_two_mod.json"), os.path.join(HERE, "fusion_two_mod.npz"))
     slicing = {}
@@ -402,6 +473,7 @@ def main():
     gen_convert(os.path.join(HERE, "convert.npz"))
     gen_glue(os.path.join(HERE, "glue.json"), os.path.join(HERE, "glue_unet64.npz"))
     gen_fusion(os.path.join(HERE, "fusion_two_mod.json"), os.path.join(HERE, "fusion_two_mod.npz"))
+    gen_sentinel(os.path.join(HERE, "sentinel.json"), os.path.join(HERE, "sentinel.npz"))
 
 
 if __name__ == "__main__":

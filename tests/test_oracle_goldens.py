@@ -446,3 +446,21 @@ def _utae_state_shapes(input_dim=10, enc=(64, 64, 64, 128), dec=(32, 32, 64, 128
     conv("out_conv.conv.conv.0", dec[0], out_conv[0]); bn("out_conv.conv.conv.1", out_conv[0])
     conv("out_conv.conv.conv.3", out_conv[0], out_conv[1]); bn("out_conv.conv.conv.4", out_conv[1])
     return s
+
+
+def test_pad_collate_matches_the_reference():
+    """flair_hub.data.utils_data.padding.pad_collate_flair against the reference's own function
+    (tests/golden/gen_padding_golden.py): ragged series, an all-empty batch, stacked tensors, listed strings"""
+    from flair_hub.data.utils_data.padding import pad_collate_flair
+    d = np.load(os.path.join(GOLD, "pad_collate.npz"))
+    samples = []
+    for i in range(4):
+        samples.append({"SENTINEL2_TS": torch.tensor(d[f"in{i}_SENTINEL2_TS"]),
+                        "SENTINEL2_DATES": torch.tensor(d[f"in{i}_SENTINEL2_DATES"]),
+                        "AERIAL_RGBI": torch.tensor(d[f"in{i}_AERIAL_RGBI"]), "ID": f"tile{i}"})
+    out = pad_collate_flair(samples, pad_value=0)
+    assert out["ID"] == [f"tile{i}" for i in range(4)]
+    for k in ("SENTINEL2_TS", "SENTINEL2_DATES", "AERIAL_RGBI"):
+        assert np.array_equal(out[k].numpy(), d[f"out_{k}"]), k
+    empty = pad_collate_flair([{"SENTINEL2_TS": torch.zeros(0), "SENTINEL2_DATES": torch.zeros(0)} for _ in range(3)])
+    assert tuple(empty["SENTINEL2_TS"].shape) == tuple(d["empty_TS_shape"])
