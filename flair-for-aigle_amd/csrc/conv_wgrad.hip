@@ -73,7 +73,13 @@ struct WgradGeom {
   // write + a read of Co*taps*Ci*4 bytes in HBM; with 512 single-slab blocks that was half of the kernel time)
   static constexpr bool MERGE = (WK > 1) && (WCO * WCI == 4 || KH == 7);  // small-channel blocks keep per-group slabs
   static constexpr int MERGE_BYTES = MERGE ? WCO * WCI * (WK - 1) * TAPS * 16 * 64 * 4 : 0;
-  static constexpr int LDS_BYTES = STAGE_BYTES > MERGE_BYTES ? STAGE_BYTES : MERGE_BYTES;
+  // Double-buffered staging for the eight-wave 64 x 64-channel blocks (one block per CU): tile t+1 is stored into the
+  // other LDS image from INSIDE tile t's k loop -- the two k groups of a SIMD store at different k-steps, so one of
+  // them keeps the matrix pipe busy -- and one barrier per tile remains.  Single-buffered, every tile paid
+  // barrier + 75 KB of ds_write + barrier with no wave issuing MFMAs (27 % of a tile, tools/conv_trace.py).
+  static constexpr bool DB = (EB == 2) && MERGE && (WCO * WCI == 4) && (KH == 3) && (2 * STAGE_BYTES <= 160 * 1024);
+  static constexpr int STAGE_TOTAL = DB ? 2 * STAGE_BYTES : STAGE_BYTES;
+  static constexpr int LDS_BYTES = STAGE_TOTAL > MERGE_BYTES ? STAGE_TOTAL : MERGE_BYTES;
   static constexpr int DY_PIECES = WCO * NPX * PARTS;
   static constexpr int IN_PIECES = WCI * IH * IW * PARTS;
   static constexpr int NDP = (DY_PIECES + NTHR - 1) / NTHR;
@@ -143,6 +149,7 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
   const int khalf = lane >> 5;
   const unsigned char* dyPlane = sDy + wco * (G::NPX * G::ROWB);
   const unsigned char* inPlane = sIn + wci * (G::IH * G::IW * G::ROWB);
+  (void)0;
 
   // staging registers: the NEXT tile's global loads are issued before the MFMAs of the current tile
   ffa_u32x4 dreg[G::NDP];
@@ -266,19 +273,39 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
   int pt = split;
   if (pt < a.npt) FFA_WG_LOAD(pt)
   FFA_WTRACE(1)
-  for (; pt < a.npt; pt += a.nsplit) {
-    __syncthreads();  // previous tile's fragment reads are done
-    FFA_WTRACE(2)
-    FFA_WG_STORE()    // piece i lives at byte i*16: [plane][pixel][32 ch] is linear in the piece index
-    FFA_WTRACE(3)
+  if constexpr (G::DB) {  // the first tile's image: the only exposed store phase of the block
+    FFA_WG_STORE()
     __syncthreads();
-    FFA_WTRACE(4)
-    if (pt + a.nsplit < a.npt) FFA_WG_LOAD(pt + a.nsplit)
+  }
+  int dbuf = 0;  // DB: LDS image the current tile is read from
+  for (; pt < a.npt; pt += a.nsplit) {
+    bool store_next = false;
+    if constexpr (!G::DB) {
+      __syncthreads();  // previous tile's fragment reads are done
+      FFA_WTRACE(2)
+      FFA_WG_STORE()    // piece i lives at byte i*16: [plane][pixel][32 ch] is linear in the piece index
+      FFA_WTRACE(3)
+      __syncthreads();
+      FFA_WTRACE(4)
+      if (pt + a.nsplit < a.npt) FFA_WG_LOAD(pt + a.nsplit)
+    } else {
+      store_next = pt + a.nsplit < a.npt;
+      if (store_next) FFA_WG_LOAD(pt + a.nsplit)
+      dyPlane = smem + dbuf * G::STAGE_BYTES + wco * (G::NPX * G::ROWB);
+      inPlane = smem + dbuf * G::STAGE_BYTES + G::DY_BYTES + wci * (G::IH * G::IW * G::ROWB);
+      sDy = smem + (dbuf ^ 1) * G::STAGE_BYTES;  // where FFA_WG_STORE puts the next tile
+      sIn = sDy + G::DY_BYTES;
+    }
     FFA_WTRACE(5)
 
     // ---- K loop over the tile's pixels, 16 per step; wave wk takes steps wk, wk + WK, ...
 #pragma unroll 1
     for (int ks = wk; ks < G::KSTEPS; ks += WK) {
+      if constexpr (G::DB) {
+        // the next tile's image, from inside the k loop: k group 0 stores after its 2nd step, group 1 after its 6th
+        // (of 8), so the two waves of a SIMD are never both away from the matrix pipe
+        if (store_next && ks == wk + WK * (wk == 0 ? 2 : 6)) FFA_WG_STORE()
+      }
       const int n0 = ks * 16;
       const int py = n0 / TW, px0 = n0 % TW;
       if constexpr (EB == 2) {
@@ -341,6 +368,10 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
       }
     }
     FFA_WTRACE(6)
+    if constexpr (G::DB) {
+      __syncthreads();  // every wave is done reading this image and has stored its share of the next one
+      dbuf ^= 1;
+    }
   }
 #undef FFA_WG_LOAD
 #undef FFA_WG_LOAD_GENERIC
@@ -490,8 +521,19 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_ring_kernel(WgradArgs a) {
     const unsigned char* base = (k * 256 < G::DY_PIECES) ? dy_b : x_b;
     const unsigned lbase =
         (unsigned)__builtin_amdgcn_readfirstlane((int)(stage * STAGE_BYTES + (wave * 64 + k * 256) * 16));
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (unsigned)voff[k]),
-                                     (__attribute__((address_space(3))) void*)(smem + lbase), 16, 0, 0);
+    // inline asm, not __builtin_amdgcn_global_load_lds: with the builtin in the kernel hipcc (ROCm 7.2) drains
+    // lgkmcnt to 0 in front of every MFMA step, i.e. waits for the transpose reads it has just issued for the NEXT
+    // step (found on conv3x3_ring_kernel); the DMA's completion is waited for by hand below anyway
+    {
+      const unsigned char* src_ = base + (unsigned)voff[k];
+      const unsigned dst_ = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(smem + lbase);
+      unsigned keep_;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+          : "=&s"(keep_)
+          : "v"(src_), "s"(dst_)
+          : "memory");
+    }
   };
   auto issue_all = [&](int t, int stage) {
     prepare(t, stage);
@@ -868,7 +910,8 @@ struct WgradPlan {
   int wco, wci, wk, th, tw, rg, nsplit, ncob, ncib, CoT, CiT, npt, tiles_x, tiles_y, ring, nslab, stem;
 };
 
-static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, int B, int Ho, int Wo, WgradPlan* p) {
+static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, int B, int Ho, int Wo, WgradPlan* p,
+                       bool allow_ring = true) {
   const bool s1 = (kh == 3 && kw == 3 && stride == 1);
   const bool s2 = (kh == 3 && kw == 3 && stride == 2);
   const bool one = (kh == 1 && kw == 1 && (stride == 1 || stride == 2));
@@ -916,10 +959,19 @@ static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, in
   // 128-pixel tile does not arrive within two tiles of matrix work.  Kept selectable (FFA_WGRAD_RING=1) for the
   // next round's work on the fill path (full-line piece order, deeper ring); off by default.
   static const bool ring_enabled = getenv("FFA_WGRAD_RING") && getenv("FFA_WGRAD_RING")[0] == '1';
-  p->ring = (ring_enabled && false && s1 && !f32 && p->wco == 2 && p->wci == 2 && Ho % p->th == 0 && Wo % p->tw == 0 &&
-             (long long)B * Ho * Wo * (Co > Ci ? Co : Ci) * 2 < (1LL << 31))
+  // the ring kernel walks 128-pixel tiles (4 x 32 / 8 x 16) with ONE k group per block: half the rows of the
+  // 256-pixel tiles chosen above for the eight-wave kernel
+  const int ring_th = p->th / 2;
+  p->ring = (ring_enabled && allow_ring && s1 && !f32 && p->wco == 2 && p->wci == 2 && p->wk == 2 && Ho % ring_th == 0 &&
+             Wo % p->tw == 0 && (long long)B * Ho * Wo * (Co > Ci ? Co : Ci) * 2 < (1LL << 31))
                 ? 1
                 : 0;
+  if (p->ring) {
+    p->th = ring_th;
+    p->wk = 1;
+    p->tiles_y = ffa_cdiv(Ho, p->th);
+    p->npt = B * p->tiles_x * p->tiles_y;
+  }
   const int threads = 64 * p->wco * p->wci * p->wk;
   // a split costs one f32 slab of HBM traffic; 512-thread blocks run one per CU, so their grid is kept at or
   // just below 256 blocks (a 288-block grid would need two rounds)
@@ -1021,13 +1073,12 @@ static int wgrad_impl(int dtype, const void* x, const void* x2, int C1, const vo
   FFA_REQUIRE(Ci % 8 == 0 && Co % 8 == 0, "conv_wgrad: channel pitch must be a multiple of 8");
   FFA_REQUIRE(Co_real <= Co && Ci_real <= Ci, "conv_wgrad: real channels exceed pitch");
   WgradPlan p;
-  if (!wgrad_plan(dtype, kh, kw, stride, Co, Ci, B, Ho, Wo, &p)) {
+  // the ring kernel's edge masks assume a one-pixel halo, and it has no two-source loader
+  if (!wgrad_plan(dtype, kh, kw, stride, Co, Ci, B, Ho, Wo, &p, pad == 1 && C1 == 0)) {
     ffa_set_error("conv_wgrad: unsupported kernel %dx%d stride %d", kh, kw, stride);
     return FFA_ERR_UNSUPPORTED;
   }
-  if (pad != 1) p.ring = 0;  // the ring kernel's edge masks assume a one-pixel halo
   if (C1 > 0) {
-    p.ring = 0;
     if (C1 % (32 * p.wci) != 0) {
       ffa_set_error("conv_wgrad_upcat: C1 = %d is not a multiple of the block's %d input channels", C1, 32 * p.wci);
       return FFA_ERR_UNSUPPORTED;

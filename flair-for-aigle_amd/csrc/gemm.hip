@@ -1,0 +1,199 @@
+// Token GEMM for the transformer layers (nn.Linear of timm's swin_transformer.py: qkv / proj / Mlp.fc1 / Mlp.fc2 /
+// PatchMerging.reduction, and PatchEmbed.proj after ffa_space_to_depth):
+//
+//   out[m][n] = act( sum_k a[m][k] * w[n][k] + bias[n] ) + residual[m][n]          bf16 in / out, f32 accumulate
+//
+// Both operands are K-contiguous (activations [M][lda], weights in nn.Linear's own [N][K] layout), which is the
+// operand order of v_mfma_f32_16x16x32_bf16: a lane's fragment is 16 contiguous bytes of one row.  The kernel forms
+// C^T = W A^T (A operand = 16 features x 32 k, B operand = 32 k x 16 tokens) so that a lane ends up with four
+// consecutive FEATURES of one token -- one 8-byte piece of an output row; the block's 128 x 128 tile is then turned
+// into whole 128-byte row segments through LDS for the bias / GELU / residual epilogue and the store.
+//
+// Block: 128 tokens x 128 features, 4 waves as 2 x 2 (64 x 64 each = 4 x 4 MFMA tiles, 64 accumulator VGPRs), BK = 64.
+// LDS: two images of (128 + 128) rows x 144 bytes (128 data + 16 pad: the 16 rows x 4 k-pieces of a fragment read hit
+// 64 distinct 4-bank groups) = 72 KB, two blocks per CU.  Pipeline: chunk c+2 is in flight from HBM into registers and
+// chunk c+1 moves registers -> LDS (other image) while chunk c feeds the matrix pipe: ONE barrier per 32 MFMAs per wave.
+// Bound: HBM for the thin early stages (K = 128: 1.5 flop per byte moved at stage 1), MFMA for K >= 512.
+#include "ffa_common.h"
+
+#define FFA_ACT_NONE 0
+#define FFA_ACT_GELU 1
+
+struct GemmArgs {
+  const ffa_bf16* a;
+  const ffa_bf16* w;
+  const float* bias;
+  const ffa_bf16* residual;
+  ffa_bf16* out;
+  long long lda, ldr, ldc;
+  int M, K, N, act, nblk_n;
+};
+
+namespace {
+constexpr int GBM = 128, GBN = 128, GBK = 64;
+constexpr int GPITCH = 144;                       // bytes per staged row
+constexpr int GIMG = (GBM + GBN) * GPITCH;        // one LDS image
+constexpr int GEP = 144;                          // epilogue row pitch (64 features bf16 + pad)
+}  // namespace
+
+__device__ __forceinline__ float gemm_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GIMG];
+  // XCD-aware order: the 8 XCDs take consecutive workgroup ids round-robin; give each XCD a contiguous run of tiles so
+  // that the feature blocks of one token panel (same A tile) share an L2
+  const int nb = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int per = nb >> 3, rem = nb & 7, xcd = id & 7, loc = id >> 3;
+    id = xcd < rem ? xcd * (per + 1) + loc : rem * (per + 1) + (xcd - rem) * per + loc;
+  }
+  const int bm = id / g.nblk_n, bn = id % g.nblk_n;
+  const int m0 = bm * GBM, n0 = bn * GBN;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n = lane & 15, grp = lane >> 4;
+
+  // staging: piece p = tid + 256 j -> row p / 8, 16-byte piece p % 8 of the chunk
+  const unsigned char* arow[4];
+  const unsigned char* wrow[4];
+  int soff[4];
+  const int pc = tid & 7;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (tid >> 3) + 32 * j;
+    int ar = m0 + r;
+    if (ar > g.M - 1) ar = g.M - 1;
+    int wr = n0 + r;
+    if (wr > g.N - 1) wr = g.N - 1;
+    arow[j] = reinterpret_cast<const unsigned char*>(g.a + (long long)ar * g.lda);
+    wrow[j] = reinterpret_cast<const unsigned char*>(g.w + (long long)wr * g.K);
+    soff[j] = r * GPITCH + pc * 16;
+  }
+  ffa_u32x4 ra[4], rw[4];
+  auto load_regs = [&](int c) {
+    int kb = (c * GBK + pc * 8) * 2;       // byte offset of this thread's piece in a row
+    const int kmax = (g.K - 8) * 2;
+    if (kb > kmax) kb = kmax;              // past the end of a ragged last chunk: any valid piece, never multiplied
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ra[j] = *reinterpret_cast<const ffa_u32x4*>(arow[j] + kb);
+      rw[j] = *reinterpret_cast<const ffa_u32x4*>(wrow[j] + kb);
+    }
+  };
+  auto store_lds = [&](int buf) {
+    unsigned char* img = smem + buf * GIMG;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *reinterpret_cast<ffa_u32x4*>(img + soff[j]) = ra[j];
+      *reinterpret_cast<ffa_u32x4*>(img + GBM * GPITCH + soff[j]) = rw[j];
+    }
+  };
+
+  ffa_f32x4 acc[4][4];  // [feature tile][token tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = ffa_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (g.K + GBK - 1) / GBK;
+  load_regs(0);
+  store_lds(0);
+  if (nk > 1) load_regs(1);
+  __syncthreads();
+  const int tok_base = (wm * 64 + n) * GPITCH + grp * 16;
+  const int fea_base = GBM * GPITCH + (wn * 64 + n) * GPITCH + grp * 16;
+  for (int c = 0; c < nk; ++c) {
+    if (c + 1 < nk) store_lds((c + 1) & 1);
+    if (c + 2 < nk) load_regs(c + 2);
+    const unsigned char* img = smem + (c & 1) * GIMG;
+    const int ksteps = (g.K - c * GBK) >= GBK ? 2 : 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks < ksteps) {
+        ffa_bf16x8 fw[4], ft[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          fw[i] = *reinterpret_cast<const ffa_bf16x8*>(img + fea_base + i * 16 * GPITCH + ks * 64);
+          ft[i] = *reinterpret_cast<const ffa_bf16x8*>(img + tok_base + i * 16 * GPITCH + ks * 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], ft[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + activation in registers, the wave's 64 x 64 tile through LDS, residual + store by rows
+  unsigned char* ep = smem + wave * (64 * GEP);
+  const int fcol0 = n0 + wn * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = fcol0 + i * 16 + grp * 4;
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && f < g.N) {
+      const float4 bv = *reinterpret_cast<const float4*>(g.bias + f);
+      b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = acc[i][j][e] + b4[e];
+        if (g.act == FFA_ACT_GELU) v[e] = gemm_gelu(v[e]);
+      }
+      uint2 pk;
+      pk.x = ffa_pack_bf16x2(v[0], v[1]);
+      pk.y = ffa_pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(ep + (j * 16 + n) * GEP + (i * 16 + grp * 4) * 2) = pk;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  const int fp = lane & 7;
+  const int col = fcol0 + fp * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int t = (lane >> 3) + 8 * j;
+    const int row = m0 + wm * 64 + t;
+    if (row < g.M && col < g.N) {
+      ffa_u32x4 v = *reinterpret_cast<const ffa_u32x4*>(ep + t * GEP + fp * 16);
+      if (g.residual) {
+        float o[8], r[8];
+        ffa_load8<ffa_bf16>(reinterpret_cast<const ffa_bf16*>(&v), o);
+        ffa_load8<ffa_bf16>(g.residual + (long long)row * g.ldr + col, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += r[e];
+        ffa_store8<ffa_bf16>(g.out + (long long)row * g.ldc + col, o);
+      } else {
+        *reinterpret_cast<ffa_u32x4*>(g.out + (long long)row * g.ldc + col) = v;
+      }
+    }
+  }
+}
+
+extern "C" int ffa_linear(int dtype, const void* a, long long lda, const void* w, const float* bias, const void* residual,
+                          long long ldr, void* out, long long ldc, int M, int K, int N, int act, hipStream_t stream) {
+  FFA_REQUIRE(dtype == FFA_BF16, "linear: only the bf16 token GEMM is built (the f32 parity mode uses ffa_conv2d 1x1)");
+  FFA_REQUIRE(a && w && out && M > 0 && K > 0 && N > 0, "linear: bad arguments");
+  FFA_REQUIRE(K % 32 == 0 && N % 8 == 0, "linear: K = %d must be a multiple of 32 and N = %d of 8", K, N);
+  FFA_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 8 == 0 && (!residual || (ldr >= N && ldr % 8 == 0)),
+              "linear: row pitches must cover the row and be multiples of 8 elements");
+  FFA_REQUIRE(act == FFA_ACT_NONE || act == FFA_ACT_GELU, "linear: unknown activation %d", act);
+  GemmArgs g;
+  g.a = (const ffa_bf16*)a;
+  g.w = (const ffa_bf16*)w;
+  g.bias = bias;
+  g.residual = (const ffa_bf16*)residual;
+  g.out = (ffa_bf16*)out;
+  g.lda = lda; g.ldr = ldr; g.ldc = ldc;
+  g.M = M; g.K = K; g.N = N; g.act = act;
+  g.nblk_n = (N + GBN - 1) / GBN;
+  const long long blocks = (long long)((M + GBM - 1) / GBM) * g.nblk_n;
+  FFA_REQUIRE(blocks < (1LL << 31), "linear: grid too large");
+  hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g);
+  return ffa_check_launch("linear");
+}

@@ -7,9 +7,10 @@ encoder_name=<encoder>, classes, in_channels[, img_size])`` and keeps either ``.
 no third-party model zoo and no weight download is involved (smp's default ``encoder_weights=
 "imagenet"`` fetch has no counterpart: weights come from the checkpoint or from the seeded init).
 
-Supported ``models.monotemp_model.arch`` values: ``resnet34-unet`` (BASELINE configs 1-3).
-Other encoder/decoder pairs of the reference (Swin + UPerNet) raise
-NotImplementedError with the arch name -- they are scheduled after the U-Net path meets its bar.
+Supported ``models.monotemp_model.arch`` values: ``resnet34-unet`` (BASELINE configs 1-3) and
+``swin_{tiny,small,base,large}_patch4_window{7,12}_{224,384}-upernet`` (the reference's default arch and the fork's zonal
+configuration; BASELINE config 4; evaluation-mode forward, see flairhip/swin.py).  Any other encoder/decoder pair
+raises NotImplementedError with the arch name.
 """
 from __future__ import annotations
 
@@ -17,9 +18,9 @@ from typing import Any, Dict
 
 import torch.nn as nn
 
-from flairhip import unet
+from flairhip import swin, unet
 
-SUPPORTED_ARCHS = {"resnet34-unet"}
+SUPPORTED_ARCHS = {"resnet34-unet", "swin_*-upernet"}
 
 
 class DecoderWrapper(nn.Module):
@@ -43,6 +44,12 @@ def _split_arch(config: Dict[str, Any]):
     return arch, encoder, decoder
 
 
+def _is_supported(encoder: str, decoder: str) -> bool:
+    if f"{encoder}-{decoder}".lower() == "resnet34-unet":
+        return True
+    return decoder.lower() == "upernet" and swin.is_swin_name(encoder)
+
+
 class FLAIR_Monotemp(nn.Module):
     """Same constructor and attributes as the reference class: ``.seg_model`` is the encoder
     (``return_type='encoder'``, exposing ``.out_channels``) or the decoder + head wrapper."""
@@ -53,9 +60,18 @@ class FLAIR_Monotemp(nn.Module):
         self.return_type = return_type
         assert self.return_type in ["encoder", "decoder"], 'return_type should be one of ["encoder", "decoder"]'
         arch, encoder, decoder = _split_arch(config)
-        if f"{encoder}-{decoder}".lower() not in SUPPORTED_ARCHS:
+        if not _is_supported(encoder, decoder):
             raise NotImplementedError(
                 f"monotemp arch '{arch}' has no libflairhip implementation yet (available: {sorted(SUPPORTED_ARCHS)})")
+        if decoder.lower() == "upernet":
+            # smp.create_model("upernet", "tu-swin_...", img_size=img_size): the Swin is built for this input size
+            if return_type == "encoder":
+                self.seg_model = swin.HipSwinEncoder(encoder, channels, img_size)
+            else:
+                dim = swin.parse_swin_name(encoder)[0]
+                enc_channels = [channels, 0] + [dim * 2 ** i for i in range(4)]
+                self.seg_model = DecoderWrapper(swin.HipUPerNetDecoder(enc_channels), swin.HipUPerNetHead(64, classes))
+            return
         if return_type == "encoder":
             self.seg_model = unet.ResNet34Encoder(channels)
         else:

@@ -76,6 +76,14 @@ SIGNATURES = {
     "ffa_temporal_aggregate": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ffa_detect_pad_images": (_i, [_p, _p, _i, _ll, _f, _p]),
     "ffa_mask_images": (_i, [_i, _p, _p, _i, _ll, _f, _p]),
+    "ffa_linear": (_i, [_i, _p, _ll, _p, _p, _p, _ll, _p, _ll, _i, _i, _i, _i, _p]),
+    "ffa_space_to_depth": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "ffa_layer_norm": (_i, [_i, _p, _p, _p, _p, _ll, _i, _f, _p]),
+    "ffa_patch_merge_norm": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "ffa_window_attention": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "ffa_gelu": (_i, [_i, _p, _p, _ll, _p]),
+    "ffa_adaptive_avg_pool": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "ffa_bilinear_slice": (_i, [_i, _p, _p, _p] + [_i] * 9 + [_p]),
     "ffa_bn_workspace_bytes": (_ll, [_i]),
     "ffa_bn_stats": (_i, [_i, _p, _ll, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _ll, _p]),
     "ffa_bn_finalize": (_i, [_p, _ll, _ll, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _ll, _p]),

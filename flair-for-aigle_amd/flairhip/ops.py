@@ -905,3 +905,113 @@ def mask_images_(x: torch.Tensor, pad: torch.Tensor, value: float = 0.0) -> torc
     _l.check(_l.load().ffa_mask_images(_dt(x), x.data_ptr(), pad.data_ptr(), N, x.numel() // N, value, _stream()),
              "mask_images")
     return x
+
+
+# --------------------------------------------------------------------------------------------------
+# Swin-Transformer / UPerNet (csrc/transformer.hip, csrc/gemm.hip)
+
+ACT_NONE, ACT_GELU = 0, 1
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Linear on the last dimension of a bf16 token tensor [..., K]: act(x w^T + bias) + residual.
+    w: bf16 [N, K] (nn.Linear.weight's layout), bias f32 [N]."""
+    if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
+        raise ValueError("linear: bf16 operands only (f32 parity mode goes through conv2d 1x1)")
+    if not x.is_contiguous() or not w.is_contiguous():
+        raise ValueError("linear: operands must be contiguous")
+    K = x.shape[-1]
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"linear: weight {tuple(w.shape)} does not match K = {K}")
+    M = x.numel() // K
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+    if residual is not None and (residual.shape != out.shape or not residual.is_contiguous()):
+        raise ValueError("linear: residual must be contiguous and shaped like the output")
+    _l.check(_l.load().ffa_linear(_dt(x), x.data_ptr(), K, w.data_ptr(), _ptr(bias), _ptr(residual), N, out.data_ptr(),
+                                  N, M, K, N, act, _stream()), "linear")
+    return out
+
+
+def space_to_depth(x: torch.Tensor, ps: int) -> torch.Tensor:
+    """[B,H,W,C] -> [B,H/ps,W/ps,ps*ps*C], channel order (dy, dx, c)"""
+    _chk_nhwc(x, "space_to_depth input")
+    B, H, W, C = x.shape
+    if H % ps or W % ps:
+        raise ValueError(f"space_to_depth: {H}x{W} is not a multiple of the patch size {ps}")
+    out = torch.empty((B, H // ps, W // ps, ps * ps * C), dtype=x.dtype, device=x.device)
+    _l.check(_l.load().ffa_space_to_depth(_dt(x), x.data_ptr(), out.data_ptr(), B, H // ps, W // ps, C, ps, _stream()),
+             "space_to_depth")
+    return out
+
+
+def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    if not x.is_contiguous():
+        raise ValueError("layer_norm: input must be contiguous")
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    _l.check(_l.load().ffa_layer_norm(_dt(x), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                      x.numel() // C, C, eps, _stream()), "layer_norm")
+    return out
+
+
+def patch_merge_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """PatchMerging's gather + LayerNorm(4C): [B,H,W,C] -> [B,H/2,W/2,4C]"""
+    _chk_nhwc(x, "patch_merge input")
+    B, H, W, C = x.shape
+    out = torch.empty((B, H // 2, W // 2, 4 * C), dtype=x.dtype, device=x.device)
+    _l.check(_l.load().ffa_patch_merge_norm(_dt(x), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B,
+                                            H, W, C, eps, _stream()), "patch_merge_norm")
+    return out
+
+
+def window_attention(qkv: torch.Tensor, qkv_bias: torch.Tensor, table: torch.Tensor, heads: int, ws: int, shift: int,
+                     scale: float) -> torch.Tensor:
+    """qkv [B,H,W,3C] -> [B,H,W,C]; table f32 [(2ws-1)^2, heads]"""
+    _chk_nhwc(qkv, "window_attention input")
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    if table.shape != ((2 * ws - 1) ** 2, heads) or table.dtype != torch.float32 or not table.is_contiguous():
+        raise ValueError("window_attention: relative position bias table must be contiguous f32 [(2ws-1)^2, heads]")
+    if qkv_bias.numel() != C3 or qkv_bias.dtype != torch.float32:
+        raise ValueError("window_attention: qkv bias must be f32 [3C]")
+    out = torch.empty((B, H, W, C), dtype=qkv.dtype, device=qkv.device)
+    _l.check(_l.load().ffa_window_attention(_dt(qkv), qkv.data_ptr(), out.data_ptr(), qkv_bias.data_ptr(),
+                                            table.data_ptr(), B, H, W, C, heads, ws, shift, scale, _stream()),
+             "window_attention")
+    return out
+
+
+def gelu(x: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(x)
+    _l.check(_l.load().ffa_gelu(_dt(x), x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "gelu")
+    return out
+
+
+def adaptive_avg_pool(x: torch.Tensor, size: int) -> torch.Tensor:
+    _chk_nhwc(x, "adaptive_avg_pool input")
+    B, H, W, C = x.shape
+    out = torch.empty((B, size, size, C), dtype=x.dtype, device=x.device)
+    _l.check(_l.load().ffa_adaptive_avg_pool(_dt(x), x.data_ptr(), out.data_ptr(), B, H, W, C, size, _stream()),
+             "adaptive_avg_pool")
+    return out
+
+
+def bilinear_slice(x: torch.Tensor, out_hw: Tuple[int, int], out: Optional[torch.Tensor] = None, offset: int = 0,
+                   addend: Optional[torch.Tensor] = None, align_corners: bool = False) -> torch.Tensor:
+    """F.interpolate(x, out_hw, 'bilinear', align_corners) (+ addend) into out[..., offset:offset + C]"""
+    _chk_nhwc(x, "bilinear_slice input")
+    B, Hi, Wi, C = x.shape
+    Ho, Wo = out_hw
+    if out is None:
+        out = torch.empty((B, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    if out.shape[:3] != (B, Ho, Wo) or not out.is_contiguous() or out.dtype != x.dtype:
+        raise ValueError("bilinear_slice: destination does not match")
+    if addend is not None and (addend.shape != (B, Ho, Wo, C) or not addend.is_contiguous()):
+        raise ValueError("bilinear_slice: addend must be dense [B,Ho,Wo,C]")
+    _l.check(_l.load().ffa_bilinear_slice(_dt(x), x.data_ptr(), _ptr(addend), out.data_ptr(), B, Hi, Wi, Ho, Wo, C,
+                                          out.shape[-1], offset, 1 if align_corners else 0, _stream()),
+             "bilinear_slice")
+    return out

@@ -167,6 +167,39 @@ int ffa_detect_pad_images(const float* x, unsigned char* pad, int N, long long p
 int ffa_mask_images(int dtype, void* x, const unsigned char* pad, int N, long long per_image, float value,
                     ffa_stream_t stream);
 
+/* ---- Swin-Transformer encoder + UPerNet decoder (the reference's default `swin_*-upernet` architecture:
+ *      configs/train/config_models.yaml:5, configs/config_model_zonal_segmentation.yaml:26, resolved through
+ *      flair_hub/models/monotemp_model.py:64-92 by smp.create_model("upernet", "tu-swin_...")).
+ *      Token tensors are NHWC [B][H][W][C]; evaluation-mode forward. ------------------------------------------- */
+#define FFA_ACT_NONE 0
+#define FFA_ACT_GELU 1
+/* nn.Linear (+ nn.GELU) (+ residual add) on tokens: out[m][n] = act(sum_k a[m][k] w[n][k] + bias[n]) + residual[m][n];
+ * w is nn.Linear.weight's own [N][K] layout in bf16.  bf16 only (the f32 parity mode runs ffa_conv2d 1x1). */
+int ffa_linear(int dtype, const void* a, long long lda, const void* w, const float* bias, const void* residual,
+               long long ldr, void* out, long long ldc, int M, int K, int N, int act, ffa_stream_t stream);
+/* PatchEmbed's Conv2d(kernel = stride = ps) as a gather: out[b][y][x][(dy*ps + dx)*C + c] = in[b][y*ps+dy][x*ps+dx][c] */
+int ffa_space_to_depth(int dtype, const void* in, void* out, int B, int Ho, int Wo, int C, int ps, ffa_stream_t stream);
+/* nn.LayerNorm(C) over rows of C contiguous channels */
+int ffa_layer_norm(int dtype, const void* x, void* y, const float* gamma, const float* beta, long long rows, int C,
+                   float eps, ffa_stream_t stream);
+/* PatchMerging's 2x2 gather + nn.LayerNorm(4C): x [B][H][W][C] -> y [B][H/2][W/2][4C] */
+int ffa_patch_merge_norm(int dtype, const void* x, void* y, const float* gamma, const float* beta, int B, int H, int W,
+                         int C, float eps, ffa_stream_t stream);
+/* SwinTransformerBlock._attn without the two projections: cyclic shift, padding to the window grid, window partition,
+ * softmax(scale q k^T + relative position bias + shift mask) v, window reverse, crop, un-shift -- by index arithmetic on
+ * qkv [B][H][W][3C] (channel = which*C + head*32 + d); qkv_bias [3C] is what a padding token projects to;
+ * table [(2 ws - 1)^2][heads] is relative_position_bias_table */
+int ffa_window_attention(int dtype, const void* qkv, void* out, const float* qkv_bias, const float* table, int B, int H,
+                         int W, int C, int heads, int ws, int shift, float scale, ffa_stream_t stream);
+/* nn.GELU() (erf form), elementwise; n a multiple of 8 */
+int ffa_gelu(int dtype, const void* x, void* y, long long n, ffa_stream_t stream);
+/* nn.AdaptiveAvgPool2d(S) of smp's PSPModule: x [B][H][W][C] -> y [B][S][S][C] */
+int ffa_adaptive_avg_pool(int dtype, const void* x, void* y, int B, int H, int W, int C, int S, ffa_stream_t stream);
+/* F.interpolate(mode="bilinear", align_corners=...) written into channels [y_off, y_off + C) of y [B][Ho][Wo][y_pitch],
+ * plus an optional dense addend [B][Ho][Wo][C] (FPNBlock: upsample + lateral) */
+int ffa_bilinear_slice(int dtype, const void* x, const void* addend, void* y, int B, int Hi, int Wi, int Ho, int Wo,
+                       int C, int y_pitch, int y_off, int align_corners, ffa_stream_t stream);
+
 /* ---- BatchNorm2d + ReLU + residual, MaxPool2d(3,2,1) (smp ResNet-34 encoder / UnetDecoder blocks;
  *      SURVEY.md Appendix C) ----------------------------------------------------------------------- */
 long long ffa_bn_workspace_bytes(int C);

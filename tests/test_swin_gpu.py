@@ -1,0 +1,262 @@
+"""Swin-Transformer + UPerNet (BASELINE config 4; the fork's zonal configuration) on the MI355X
+against the CPU oracle oracle/swin_upernet.py (torch fp32 restatement of timm's Swin + smp's UPerNet; parity unpinned,
+see its header) and, per kernel, against the torch.nn.functional op it replaces."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import helpers  # noqa: F401  (sys.path)
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ---------------------------------------------------------------------------------------------------- token GEMM
+
+@pytest.mark.parametrize("M,K,N,act,res", [
+    (256, 96, 96, 0, False), (256, 96, 288, 0, False), (300, 128, 384, 0, True), (128, 384, 96, 1, False),
+    (1024, 512, 2048, 1, False), (1024, 2048, 512, 0, True), (72, 32, 8, 0, False), (4096, 160, 136, 1, False),
+    (129, 64, 264, 0, True),
+])
+def test_linear_matches_torch(M, K, N, act, res):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(M * 7 + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    xb, wb = _bf(x), _bf(w)
+    ref = F.linear(xb.float(), wb.float(), b)
+    if act:
+        ref = F.gelu(ref)
+    if res:
+        ref = _bf(ref).float() + _bf(r).float()  # the GEMM result is rounded to bf16 before the residual add
+    y = ops.linear(xb.to(DEV), wb.to(DEV), b.to(DEV), act=act, residual=None if r is None else _bf(r).to(DEV))
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err
+    # no-bias, in-place residual
+    if res:
+        rr = _bf(r).to(DEV).clone()
+        y2 = ops.linear(xb.to(DEV), wb.to(DEV), None, residual=rr, out=rr)
+        ref2 = _bf(F.linear(xb.float(), wb.float())).float() + _bf(r).float()
+        assert (y2.float().cpu() - ref2).abs().max().item() <= 2e-2 * max(1.0, ref2.abs().max().item())
+
+
+def test_linear_rejects_bad_shapes():
+    from flairhip import ops
+    from flairhip.lib import FlairHipError
+    x = torch.zeros(64, 48, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(64, 48, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(FlairHipError):
+        ops.linear(x, w)  # K not a multiple of 32
+    with pytest.raises(ValueError):
+        ops.linear(x.float(), w.float())
+
+
+# ---------------------------------------------------------------------------------------------------- small kernels
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [96, 128, 1024, 4096])
+def test_layer_norm(dtype, C):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(2, 5, 7, C, generator=g) * 2 + 0.5).to(dtype)
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    ref = F.layer_norm(x.float(), (C,), w, b, 1e-5)
+    y = ops.layer_norm(x.to(DEV), w.to(DEV), b.to(DEV)).float().cpu()
+    tol = 2e-5 if dtype == torch.float32 else 4e-2
+    assert (y - ref).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_patch_merge_norm(dtype):
+    from flairhip import ops
+    from oracle.swin_upernet import PatchMerging
+    g = torch.Generator().manual_seed(3)
+    C = 96
+    x = torch.randn(2, 8, 12, C, generator=g).to(dtype)
+    pm = PatchMerging(C)
+    pm.norm.weight.data = torch.rand(4 * C, generator=g) + 0.5
+    pm.norm.bias.data = torch.randn(4 * C, generator=g)
+    xf = x.float()
+    B, H, W, _ = xf.shape
+    gathered = xf.reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 4, 2, 5).flatten(3)
+    ref = pm.norm(gathered).detach()
+    y = ops.patch_merge_norm(x.to(DEV), pm.norm.weight.data.to(DEV), pm.norm.bias.data.to(DEV)).float().cpu()
+    assert y.shape == ref.shape
+    assert (y - ref).abs().max().item() <= (2e-5 if dtype == torch.float32 else 4e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_space_to_depth_and_gelu_and_pool(dtype):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 8, 12, 16, generator=g).to(dtype)
+    y = ops.space_to_depth(x.to(DEV), 4).cpu()
+    ref = x.reshape(2, 2, 4, 3, 4, 16).permute(0, 1, 3, 2, 4, 5).reshape(2, 2, 3, 256)
+    assert torch.equal(y, ref)
+    z = ops.gelu(x.to(DEV)).float().cpu()
+    assert (z - F.gelu(x.float())).abs().max().item() <= (1e-6 if dtype == torch.float32 else 2e-2)
+    big = torch.randn(2, 16, 16, 32, generator=g).to(dtype)
+    for s in (1, 2, 3, 6):
+        p = ops.adaptive_avg_pool(big.to(DEV), s).float().cpu()
+        ref = F.adaptive_avg_pool2d(big.float().permute(0, 3, 1, 2), s).permute(0, 2, 3, 1)
+        assert (p - ref).abs().max().item() <= (1e-5 if dtype == torch.float32 else 1e-2), s
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("align", [False, True])
+@pytest.mark.parametrize("hw_in,hw_out", [((4, 4), (16, 16)), ((6, 6), (16, 16)), ((16, 16), (16, 16)),
+                                           ((32, 32), (16, 16)), ((1, 1), (16, 16)), ((8, 12), (32, 48))])
+def test_bilinear_slice(dtype, align, hw_in, hw_out):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(11)
+    C = 16
+    x = torch.randn(2, *hw_in, C, generator=g).to(dtype)
+    add = torch.randn(2, *hw_out, C, generator=g).to(dtype)
+    ref = F.interpolate(x.float().permute(0, 3, 1, 2), size=hw_out, mode="bilinear", align_corners=align)
+    ref = ref.permute(0, 2, 3, 1)
+    wide = torch.full((2, *hw_out, 48), 7.0, dtype=dtype, device=DEV)
+    ops.bilinear_slice(x.to(DEV), hw_out, out=wide, offset=16, align_corners=align)
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    got = wide.float().cpu()
+    assert (got[..., 16:32] - ref).abs().max().item() <= tol
+    assert torch.all(got[..., :16] == 7.0) and torch.all(got[..., 32:] == 7.0)
+    y = ops.bilinear_slice(x.to(DEV), hw_out, addend=add.to(DEV), align_corners=align).float().cpu()
+    assert (y - (ref + add.float())).abs().max().item() <= 2 * tol
+
+
+# ---------------------------------------------------------------------------------------------------- window attention
+
+def _attention_reference(qkv, bias, table, heads, ws, shift):
+    """timm's SwinTransformerBlock._attn between the two projections, on a given qkv tensor: padding tokens project to
+    the qkv bias (norm1's output is zero-padded before the projection)."""
+    from oracle.swin_upernet import relative_position_index, shifted_window_mask, window_partition, window_reverse
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    x = qkv
+    if shift:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
+    ph, pw = (ws - H % ws) % ws, (ws - W % ws) % ws
+    Hp, Wp = H + ph, W + pw
+    full = bias.view(1, 1, 1, C3).expand(B, Hp, Wp, C3).clone()
+    full[:, :H, :W] = x
+    xw = window_partition(full, ws).view(-1, ws * ws, C3)
+    N = ws * ws
+    q, k, v = xw.reshape(-1, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4).unbind(0)
+    attn = (q * (C // heads) ** -0.5) @ k.transpose(-2, -1)
+    rpb = table[relative_position_index(ws).view(-1)].view(N, N, -1).permute(2, 0, 1)
+    attn = attn + rpb.unsqueeze(0)
+    if shift:
+        mask = shifted_window_mask(Hp, Wp, ws, shift)
+        nW = mask.shape[0]
+        attn = (attn.view(-1, nW, heads, N, N) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, N, N)
+    out = (attn.softmax(-1) @ v).transpose(1, 2).reshape(-1, ws, ws, C)
+    out = window_reverse(out, ws, Hp, Wp)[:, :H, :W]
+    if shift:
+        out = torch.roll(out, shifts=(shift, shift), dims=(1, 2))
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,W,heads,ws,shift", [
+    (14, 14, 3, 7, 0), (14, 14, 3, 7, 3), (16, 16, 3, 7, 3), (16, 20, 4, 7, 0), (8, 8, 6, 8, 0), (4, 4, 3, 4, 0),
+    (24, 24, 4, 12, 6), (32, 32, 4, 12, 6), (32, 32, 4, 12, 0), (16, 16, 8, 12, 6), (12, 12, 32, 12, 0),
+])
+def test_window_attention(dtype, H, W, heads, ws, shift):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(H * 31 + ws + shift)
+    C = heads * 32
+    qkv = torch.randn(2, H, W, 3 * C, generator=g).to(dtype)
+    bias = torch.randn(3 * C, generator=g)
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g) * 0.5
+    bias_used = bias if dtype == torch.float32 else _bf(bias).float()
+    ref = _attention_reference(qkv.float(), bias_used, table, heads, ws, shift)
+    y = ops.window_attention(qkv.to(DEV), bias.to(DEV), table.to(DEV), heads, ws, shift, 32 ** -0.5).float().cpu()
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert (y - ref).abs().max().item() <= tol
+
+
+# ---------------------------------------------------------------------------------------------------- whole model
+
+def _randomise(oracle, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in oracle.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = torch.rand(m.weight.shape, generator=g) * 0.5 + 0.75
+            m.bias.data = torch.randn(m.bias.shape, generator=g) * 0.1
+            m.running_mean.data = torch.randn(m.bias.shape, generator=g) * 0.1
+            m.running_var.data = torch.rand(m.bias.shape, generator=g) * 0.5 + 0.75
+        elif isinstance(m, torch.nn.LayerNorm):
+            m.weight.data = torch.rand(m.weight.shape, generator=g) * 0.5 + 0.75
+            m.bias.data = torch.randn(m.bias.shape, generator=g) * 0.1
+        elif isinstance(m, torch.nn.Linear):
+            m.weight.data = torch.randn(m.weight.shape, generator=g) * (1.0 / math.sqrt(m.weight.shape[1]))
+            if m.bias is not None:
+                m.bias.data = torch.randn(m.bias.shape, generator=g) * 0.1
+    for n, p in oracle.named_parameters():
+        if n.endswith("relative_position_bias_table"):
+            p.data = torch.randn(p.shape, generator=g) * 0.5
+    oracle.segmentation_head[0].bias.data = torch.randn(oracle.segmentation_head[0].bias.shape, generator=g) * 0.1
+
+
+@pytest.mark.parametrize("name,ch,size", [
+    ("swin_tiny_patch4_window7_224", 5, 128),       # maps 32 / 16 / 8 / 4: padding 32 -> 35, 16 -> 21, 8 -> 14, window 4
+    ("swin_base_patch4_window12_384", 3, 256),      # maps 64 / 32 / 16 / 8: 64 -> 72, 32 -> 36, 16 -> 24, window 8
+])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_swin_upernet_matches_oracle(name, ch, size, precision):
+    from flairhip import ops
+    from flairhip.swin import SwinUPerNet
+    from oracle.swin_upernet import SwinUPerNet as OracleNet
+    torch.manual_seed(1)
+    oracle = OracleNet(name, ch, 19, size).eval()
+    _randomise(oracle, 7)
+    model = SwinUPerNet(name, ch, 19, size)
+    missing, unexpected = model.load_state_dict(oracle.state_dict(), strict=True)
+    assert not missing and not unexpected
+    model = model.to(DEV).eval()
+    dtype = torch.float32 if precision == "fp32" else torch.bfloat16
+    x = torch.randn(2, ch, size, size, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        ref = oracle(x)
+        feats_ref = oracle.encoder(x)
+        xn = ops.nchw_to_nhwc(x.to(DEV), dtype, ops.pad_channels(ch))
+        feats = model.encoder(xn)
+        y = model(xn)
+    assert [f.shape[-1] for f in feats] == [ops.pad_channels(ch)] + oracle.encoder.out_channels[1:]
+    assert feats[1].shape == (2, size // 2, size // 2, 0)
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    for f, fr in zip(feats[2:], feats_ref[2:]):
+        got = f.float().cpu().permute(0, 3, 1, 2)
+        assert got.shape == fr.shape
+        assert rel(got, fr) <= (2e-5 if precision == "fp32" else 3e-2)
+    logits = y[..., :19].float().cpu().permute(0, 3, 1, 2)
+    assert logits.shape == ref.shape
+    if precision == "fp32":
+        assert (logits - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+        assert torch.equal(logits.argmax(1), ref.argmax(1)) or (logits.argmax(1) == ref.argmax(1)).float().mean() > 0.9999
+    else:
+        assert rel(logits, ref) <= 4e-2
+        assert (logits.argmax(1) == ref.argmax(1)).float().mean().item() >= 0.97
+
+
+def test_swin_state_dict_accepts_timm_spelling_and_training_refuses():
+    from flairhip.swin import SwinUPerNet
+    m = SwinUPerNet("swin_tiny_patch4_window7_224", 3, 5, 64)
+    sd = {k.replace("layers_", "layers."): v for k, v in m.state_dict().items()}
+    assert any(".layers." in k for k in sd)
+    m2 = SwinUPerNet("swin_tiny_patch4_window7_224", 3, 5, 64)
+    m2.load_state_dict(sd, strict=True)
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    m2 = m2.to(DEV).train()
+    with pytest.raises(NotImplementedError):
+        m2.encoder(torch.zeros(1, 64, 64, 16, device=DEV, dtype=torch.bfloat16))
