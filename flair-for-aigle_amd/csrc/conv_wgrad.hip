@@ -73,13 +73,7 @@ struct WgradGeom {
   // write + a read of Co*taps*Ci*4 bytes in HBM; with 512 single-slab blocks that was half of the kernel time)
   static constexpr bool MERGE = (WK > 1) && (WCO * WCI == 4 || KH == 7);  // small-channel blocks keep per-group slabs
   static constexpr int MERGE_BYTES = MERGE ? WCO * WCI * (WK - 1) * TAPS * 16 * 64 * 4 : 0;
-  // Double-buffered staging for the eight-wave 64 x 64-channel blocks (one block per CU): tile t+1 is stored into the
-  // other LDS image from INSIDE tile t's k loop -- the two k groups of a SIMD store at different k-steps, so one of
-  // them keeps the matrix pipe busy -- and one barrier per tile remains.  Single-buffered, every tile paid
-  // barrier + 75 KB of ds_write + barrier with no wave issuing MFMAs (27 % of a tile, tools/conv_trace.py).
-  static constexpr bool DB = (EB == 2) && MERGE && (WCO * WCI == 4) && (KH == 3) && (2 * STAGE_BYTES <= 160 * 1024);
-  static constexpr int STAGE_TOTAL = DB ? 2 * STAGE_BYTES : STAGE_BYTES;
-  static constexpr int LDS_BYTES = STAGE_TOTAL > MERGE_BYTES ? STAGE_TOTAL : MERGE_BYTES;
+  static constexpr int LDS_BYTES = STAGE_BYTES > MERGE_BYTES ? STAGE_BYTES : MERGE_BYTES;
   static constexpr int DY_PIECES = WCO * NPX * PARTS;
   static constexpr int IN_PIECES = WCI * IH * IW * PARTS;
   static constexpr int NDP = (DY_PIECES + NTHR - 1) / NTHR;
@@ -149,7 +143,6 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
   const int khalf = lane >> 5;
   const unsigned char* dyPlane = sDy + wco * (G::NPX * G::ROWB);
   const unsigned char* inPlane = sIn + wci * (G::IH * G::IW * G::ROWB);
-  (void)0;
 
   // staging registers: the NEXT tile's global loads are issued before the MFMAs of the current tile
   ffa_u32x4 dreg[G::NDP];
@@ -273,39 +266,19 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
   int pt = split;
   if (pt < a.npt) FFA_WG_LOAD(pt)
   FFA_WTRACE(1)
-  if constexpr (G::DB) {  // the first tile's image: the only exposed store phase of the block
-    FFA_WG_STORE()
-    __syncthreads();
-  }
-  int dbuf = 0;  // DB: LDS image the current tile is read from
   for (; pt < a.npt; pt += a.nsplit) {
-    bool store_next = false;
-    if constexpr (!G::DB) {
-      __syncthreads();  // previous tile's fragment reads are done
-      FFA_WTRACE(2)
-      FFA_WG_STORE()    // piece i lives at byte i*16: [plane][pixel][32 ch] is linear in the piece index
-      FFA_WTRACE(3)
-      __syncthreads();
-      FFA_WTRACE(4)
-      if (pt + a.nsplit < a.npt) FFA_WG_LOAD(pt + a.nsplit)
-    } else {
-      store_next = pt + a.nsplit < a.npt;
-      if (store_next) FFA_WG_LOAD(pt + a.nsplit)
-      dyPlane = smem + dbuf * G::STAGE_BYTES + wco * (G::NPX * G::ROWB);
-      inPlane = smem + dbuf * G::STAGE_BYTES + G::DY_BYTES + wci * (G::IH * G::IW * G::ROWB);
-      sDy = smem + (dbuf ^ 1) * G::STAGE_BYTES;  // where FFA_WG_STORE puts the next tile
-      sIn = sDy + G::DY_BYTES;
-    }
+    __syncthreads();  // previous tile's fragment reads are done
+    FFA_WTRACE(2)
+    FFA_WG_STORE()    // piece i lives at byte i*16: [plane][pixel][32 ch] is linear in the piece index
+    FFA_WTRACE(3)
+    __syncthreads();
+    FFA_WTRACE(4)
+    if (pt + a.nsplit < a.npt) FFA_WG_LOAD(pt + a.nsplit)
     FFA_WTRACE(5)
 
     // ---- K loop over the tile's pixels, 16 per step; wave wk takes steps wk, wk + WK, ...
 #pragma unroll 1
     for (int ks = wk; ks < G::KSTEPS; ks += WK) {
-      if constexpr (G::DB) {
-        // the next tile's image, from inside the k loop: k group 0 stores after its 2nd step, group 1 after its 6th
-        // (of 8), so the two waves of a SIMD are never both away from the matrix pipe
-        if (store_next && ks == wk + WK * (wk == 0 ? 2 : 6)) FFA_WG_STORE()
-      }
       const int n0 = ks * 16;
       const int py = n0 / TW, px0 = n0 % TW;
       if constexpr (EB == 2) {
@@ -368,10 +341,6 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
       }
     }
     FFA_WTRACE(6)
-    if constexpr (G::DB) {
-      __syncthreads();  // every wave is done reading this image and has stored its share of the next one
-      dbuf ^= 1;
-    }
   }
 #undef FFA_WG_LOAD
 #undef FFA_WG_LOAD_GENERIC

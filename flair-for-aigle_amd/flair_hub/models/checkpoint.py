@@ -5,7 +5,8 @@
 
 Behaviour kept: .safetensors or torch formats; 'model.' prefix stripped when the module has none; a task head
 whose class count differs from the config is re-initialised (Xavier weight, zero bias), as is any other
-tensor whose shape disagrees; strict=False load; SystemExit on a bad path unless exit_on_fail=False.
+tensor whose shape disagrees -- except a Swin ``relative_position_bias_table``, which is resized (bicubic) to the
+model's window (:33-56, :265-271); strict=False load; SystemExit on a bad path unless exit_on_fail=False.
 Added: encoder keys of smp's timm-universal variant (``...seg_model.model.conv1.weight``) are accepted,
 because the reference's constructor fallback (monotemp_model.py:67-92) can produce either spelling.
 """
@@ -13,6 +14,7 @@ from __future__ import annotations
 
 import logging
 import os
+import re
 from typing import Any, Dict
 
 import torch
@@ -30,6 +32,22 @@ def _fresh_like(t: torch.Tensor, key: str) -> torch.Tensor:
     return p
 
 
+def interpolate_bias_table(ckpt_tensor: torch.Tensor, model_tensor: torch.Tensor) -> torch.Tensor:
+    """Swin `relative_position_bias_table` [(2w-1)^2, heads] of a checkpoint trained with another window size:
+    bicubic resize (align_corners=False) of the (2w-1) x (2w-1) table per head, as the reference does at load time
+    (flair_hub/models/checkpoint.py:33-56).  Host-side, once per load."""
+    old_len, heads = ckpt_tensor.shape
+    new_len = model_tensor.shape[0]
+    if old_len == new_len:
+        return ckpt_tensor
+    so, sn = int(old_len ** 0.5), int(new_len ** 0.5)
+    if so * so != old_len or sn * sn != new_len:
+        raise ValueError(f"relative position bias tables must be square: {old_len} -> {new_len}")
+    t = ckpt_tensor.reshape(1, so, so, heads).permute(0, 3, 1, 2)
+    t = torch.nn.functional.interpolate(t, size=(sn, sn), mode="bicubic", align_corners=False)
+    return t.permute(0, 2, 3, 1).reshape(new_len, heads)
+
+
 def _read(path: str) -> Dict[str, torch.Tensor]:
     if path.endswith(".safetensors"):
         from safetensors.torch import load_file
@@ -45,6 +63,10 @@ def normalize_keys(state: Dict[str, torch.Tensor], model_keys) -> Dict[str, torc
         state = {(k[len("model."):] if k.startswith("model.") else k): v for k, v in state.items()}
     out = {}
     for k, v in state.items():
+        if k not in model_keys and ".layers." in k:  # timm's un-flattened Swin spelling next to FeatureListNet's
+            alt = re.sub(r"\.layers\.(\d+)\.", r".layers_\1.", k)
+            if alt in model_keys:
+                k = alt
         if k not in model_keys and ".seg_model.model." in k:
             alt = k.replace(".seg_model.model.", ".seg_model.", 1)
             if alt in model_keys:
@@ -76,6 +98,13 @@ def load_checkpoint(conf: Dict[str, Any], seg_module: nn.Module, exit_on_fail: b
                 logger.info("head of task '%s' re-initialised (%s classes)", task, n_classes)
     for k in list(state):
         if k in model_dict and state[k].shape != model_dict[k].shape:
+            if "relative_position_bias_table" in k:
+                try:
+                    state[k] = interpolate_bias_table(state[k].float(), model_dict[k]).to(model_dict[k].dtype)
+                    logger.info("interpolated %s: %s -> %s", k, tuple(state[k].shape), tuple(model_dict[k].shape))
+                    continue
+                except ValueError as e:
+                    logger.info("interpolation failed for %s (%s): re-initialised", k, e)
             logger.info("shape mismatch for %s: checkpoint %s vs model %s -> re-initialised", k,
                         tuple(state[k].shape), tuple(model_dict[k].shape))
             state[k] = _fresh_like(model_dict[k], k) if model_dict[k].is_floating_point() else model_dict[k].clone()

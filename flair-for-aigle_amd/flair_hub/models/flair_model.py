@@ -77,11 +77,24 @@ class FusionHandler(nn.Module):
                                       ":497-502) is not built; use one time-series modality or add an aerial one")
         # case 4 (:504-547): a U-TAE branch contributes its decoder maps, coarse to fine, one per aerial stage (the
         # reference zips them in list order, flair_model.py:514-531); every map is resized to the stage it meets
-        nstage = len(target_fm_maps)
-        fused = [target_fm_maps[0]]
-        for s in range(1, nstage):
-            th, tw = target_fm_maps[s].shape[1], target_fm_maps[s].shape[2]
-            xs = [hnn.bilinear(feature_maps[m][s], (th, tw)) for m in active]
+        def strip(maps):  # the [input, 0-channel placeholder] pair of a transformer-style encoder (:508-518)
+            maps = list(maps)
+            if len(maps) > 2 and (maps[0].shape[-1] == 0 or maps[1].shape[-1] == 0):
+                return maps[:2], maps[2:]
+            return [], maps
+        lead, target = strip(target_fm_maps)
+        per_mod = {}
+        for m in active:
+            maps = strip(feature_maps[m])[1]
+            if len(maps) != len(target):  # (:520-521)
+                maps = [maps[0]] * (len(target) - len(maps)) + maps
+            per_mod[m] = maps
+        # with a placeholder pair every real stage is mixed; otherwise stage 0 (the input-resolution identity feature,
+        # which every decoder of this build drops) keeps the first modality's tensor
+        fused = list(lead) if lead else [target[0]]
+        for s in range(0 if lead else 1, len(target)):
+            th, tw = target[s].shape[1], target[s].shape[2]
+            xs = [hnn.bilinear(per_mod[m][s], (th, tw)) for m in active]
             splits = [self.stage_channels[m][s] for m in active]
             fused.append(hnn.fusion_conv1x1(xs, splits, self.conv_f[s]))
         return fused
@@ -149,7 +162,10 @@ class FLAIR_HUB_Model(nn.Module):
         if has_mono:
             # channels per stage of every modality (reference calc_backbones_channels :290-314): the aerial stages, and
             # for a U-TAE branch its decoder widths reversed (its maps come coarse to fine)
-            stage_channels = {m: list(self.encoders[m].seg_model.out_channels) for m in self.encoders
+            def real_stages(ch):  # smp's transformer-style encoders lead with [in, 0]: both dropped (reference :302-306)
+                ch = list(ch)
+                return ch[2:] if len(ch) > 2 and (ch[0] == 0 or ch[1] == 0) else ch
+            stage_channels = {m: real_stages(self.encoders[m].seg_model.out_channels) for m in self.encoders
                               if m in self.mono_keys}
             for m in active_multi:
                 stage_channels[m] = list(config["models"]["multitemp_model"]["decoder_widths"])[::-1]

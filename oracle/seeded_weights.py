@@ -63,3 +63,28 @@ def fill_utae_state_dict(state_dict, seed: int = 4321):
             v = torch.randn(ref.shape, generator=g) * 0.1
         out[key] = v.to(ref.dtype)
     return out
+
+
+def fill_swin_state_dict(state_dict, seed: int = 2468):
+    """Swin-Transformer + UPerNet models: LayerNorm / BatchNorm affine weights 1-D, nn.Linear weights 2-D, convolutions
+    4-D, `relative_position_bias_table` 2-D without a '.weight' suffix.  Everything else as fill_state_dict."""
+    out = {}
+    for key in sorted(state_dict.keys()):
+        ref = state_dict[key]
+        g = torch.Generator().manual_seed(seed + (zlib.crc32(key.encode()) & 0x7FFFFFF))
+        if key.endswith("num_batches_tracked"):
+            v = torch.zeros_like(ref)
+        elif key.endswith("relative_position_bias_table"):
+            v = torch.randn(ref.shape, generator=g) * 0.5
+        elif key.endswith("running_var"):
+            v = torch.rand(ref.shape, generator=g) * 0.5 + 0.75
+        elif key.endswith("running_mean"):
+            v = torch.randn(ref.shape, generator=g) * 0.1
+        elif key.endswith(".weight") and ref.ndim >= 2:
+            v = torch.randn(ref.shape, generator=g) * (1.0 / ref[0].numel()) ** 0.5
+        elif key.endswith(".weight"):
+            v = torch.rand(ref.shape, generator=g) * 0.5 + 0.75
+        else:
+            v = torch.randn(ref.shape, generator=g) * 0.1
+        out[key] = v.to(ref.dtype)
+    return out

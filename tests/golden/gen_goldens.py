@@ -9,12 +9,13 @@ small stand-in modules injected into sys.modules for those imports ONLY inside t
     window of the scenario; rasterio.transform.array_bounds -> the affine formula rasterio uses
   * geopandas.GeoDataFrame -> records list; shapely.geometry.box -> bounds tuple
   * pytorch_lightning.LightningModule -> nn.Module with .log/.device; torchmetrics -> no-op metrics
-  * segmentation_models_pytorch.create_model -> oracle/unet_resnet34.UnetResNet34 (the conv stack itself
-    is third-party code absent from the reference tree; only the reference's GLUE around it is pinned here)
+  * segmentation_models_pytorch.create_model -> oracle/unet_resnet34.UnetResNet34 or oracle/swin_upernet.SwinUPerNet
+    (the network itself is third-party code absent from the reference tree; only the reference's GLUE around it is
+    pinned here)
 Only data (inputs + the reference's outputs) is written; no reference source is copied.  The fixtures are
 committed; this script is not run on the GPU box (the reference does not travel).
 
-Usage:  python tests/golden/gen_goldens.py [fusion | sentinel]
+Usage:  python tests/golden/gen_goldens.py [fusion | sentinel | swin]
 """
 from __future__ import annotations
 
@@ -166,6 +167,13 @@ def install_stubs():
     from oracle.unet_resnet34 import UnetResNet34
 
     def create_model(arch, encoder_name, classes, in_channels, img_size=None, **kw):
+        if arch == "upernet":
+            # smp's own encoder table has no Swin: the reference's first call raises KeyError and it retries with the
+            # timm-universal prefix (monotemp_model.py:67-83)
+            if not encoder_name.startswith("tu-"):
+                raise KeyError(encoder_name)
+            from oracle.swin_upernet import SwinUPerNet
+            return SwinUPerNet(encoder_name, in_channels, classes, img_size if img_size is not None else 512)
         if img_size is not None:
             raise TypeError("img_size")  # what smp 0.4.0's Unet constructor does (SURVEY.md Appendix C caveat)
         assert arch == "unet" and encoder_name.replace("tu-", "") == "resnet34", (arch, encoder_name)
@@ -458,8 +466,47 @@ def gen_sentinel(path_json, path_npz):
     json.dump(info, open(path_json, "w"), indent=1)
 
 
+def gen_swin(path_json, path_npz):
+    """The reference's glue around a transformer-style encoder (smp's [input, 0-channel placeholder, f4, f8, f16, f32]
+    feature list): FLAIR_HUB_Model.forward in evaluation mode with two Swin-T encoders (aerial 96x96x5 + DEM 64x64x2:
+    every stage aligned by a factor 1.5), FusionHandler's placeholder stripping (flair_model.py:506-545), two UPerNet
+    task decoders and an auxiliary aerial decoder -- plus checkpoint.interpolate_bias_table (:33-56) on seeded tables.
+    oracle/swin_upernet.py stands in for smp / timm (absent); the GLUE is the reference's own code."""
+    from flair_hub.models.checkpoint import interpolate_bias_table
+    from flair_hub.tasks.module_setup import build_segmentation_module
+    from oracle.seeded_weights import checksum, fill_swin_state_dict
+    cfg = _load_cfgs().fusion_unet_config(precision="fp32")
+    cfg["models"]["monotemp_model"]["arch"] = "swin_tiny_patch4_window7_224-upernet"
+    torch.manual_seed(2025)
+    task = build_segmentation_module(cfg, {"AERIAL_RGBI": 96, "DEM_ELEV": 64}, stage="train")
+    task.model.load_state_dict(fill_swin_state_dict(task.model.state_dict()))
+    g = torch.Generator().manual_seed(29)
+    xa = torch.randn(2, 5, 96, 96, generator=g)
+    xd = torch.randn(2, 2, 64, 64, generator=g)
+    batch = {"AERIAL_RGBI": xa, "DEM_ELEV": xd,
+             "AERIAL_LABEL-COSIA": torch.zeros(2, 19, 96, 96), "ALL_LABEL-LPIS": torch.zeros(2, 96, 96, dtype=torch.long)}
+    task.eval()
+    with torch.no_grad():
+        lt, la = task.model(batch)
+    out = dict(x_aerial=xa.numpy(), x_dem=xd.numpy(), logits_cosia=lt["AERIAL_LABEL-COSIA"].numpy(),
+               logits_lpis=lt["ALL_LABEL-LPIS"][:1].numpy(),
+               logits_aux_cosia=la["aux_AERIAL_RGBI_AERIAL_LABEL-COSIA"][:1].numpy())
+    for i, (n_old, n_new, heads) in enumerate([(23, 15, 4), (13, 23, 3), (13, 13, 6)]):
+        src = torch.randn(n_old * n_old, heads, generator=g)
+        out[f"table{i}_in"] = src.numpy()
+        out[f"table{i}_out"] = interpolate_bias_table(src, torch.zeros(n_new * n_new, heads)).numpy()
+    np.savez_compressed(path_npz, **out)
+    info = {"weights_checksum": checksum(task.model.state_dict()), "logit_keys": sorted(lt.keys()),
+            "aux_keys": sorted(la.keys()), "state_dict_keys": sorted(task.model.state_dict().keys()),
+            "encoder_out_channels": list(task.model.encoders["AERIAL_RGBI"].seg_model.out_channels)}
+    json.dump(info, open(path_json, "w"), indent=1)
+    print("  swin:", {k: tuple(v.shape) for k, v in lt.items()}, len(info["state_dict_keys"]), "keys")
+
+
 def main():
     install_stubs()
+    if sys.argv[1:] == ["swin"]:
+        return gen_swin(os.path.join(HERE, "swin_two_mod.json"), os.path.join(HERE, "swin_two_mod.npz"))
     if sys.argv[1:] == ["sentinel"]:
         return gen_sentinel(os.path.join(HERE, "sentinel.json"), os.path.join(HERE, "sentinel.npz"))
     if sys.argv[1:] == ["fusion"]:  # regenerate only the multi-modality fixture

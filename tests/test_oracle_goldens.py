@@ -464,3 +464,51 @@ def test_pad_collate_matches_the_reference():
         assert np.array_equal(out[k].numpy(), d[f"out_{k}"]), k
     empty = pad_collate_flair([{"SENTINEL2_TS": torch.zeros(0), "SENTINEL2_DATES": torch.zeros(0)} for _ in range(3)])
     assert tuple(empty["SENTINEL2_TS"].shape) == tuple(d["empty_TS_shape"])
+
+
+# ---- Swin-Transformer + UPerNet: what can be pinned without timm / smp ------------------------
+
+def test_swin_upernet_oracle_parameter_count_matches_the_published_model():
+    """/root/reference/README.md:413: LC-A (aerial only, swin_base_patch4_window12_384 + UPerNet) has 89.4 M parameters"""
+    import torch
+    from oracle.swin_upernet import SwinUPerNet, count_parameters
+    with torch.device("meta"):
+        n3 = count_parameters(SwinUPerNet("swin_base_patch4_window12_384", 3, 19, 512))
+        n5 = count_parameters(SwinUPerNet("swin_base_patch4_window12_384", 5, 19, 512))
+    assert round(n3 / 1e6, 1) == 89.4 and round(n5 / 1e6, 1) == 89.4
+    o = SwinUPerNet("swin_tiny_patch4_window7_224", 5, 19, 64)
+    assert o.encoder.out_channels == [5, 0, 96, 192, 384, 768]  # smp's placeholder convention (flair_model.py:302-306)
+    assert tuple(o.state_dict()["encoder.model.layers_3.blocks.1.attn.relative_position_bias_table"].shape) == (9, 24)
+
+
+def test_bias_table_interpolation_matches_the_reference():
+    """tests/golden/swin_two_mod.npz table*: the reference's checkpoint.interpolate_bias_table (:33-56)"""
+    import numpy as np
+    import torch
+    from flair_hub.models.checkpoint import interpolate_bias_table
+    d = np.load(os.path.join(GOLD, "swin_two_mod.npz"))
+    for i in range(3):
+        src, ref = torch.from_numpy(d[f"table{i}_in"]), d[f"table{i}_out"]
+        got = interpolate_bias_table(src, torch.zeros(ref.shape)).numpy()
+        assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_checkpoint_loader_resizes_swin_bias_tables(tmp_path):
+    """a checkpoint trained at another window size loads: tables resized, everything else copied, `layers.N` accepted"""
+    import torch
+    from safetensors.torch import save_file
+    from flair_hub.models.checkpoint import interpolate_bias_table, load_checkpoint
+    from flairhip.swin import SwinUPerNet
+    src = SwinUPerNet("swin_tiny_patch4_window7_224", 3, 19, 256)   # stage maps 64 / 32 / 16 / 8: window 7 everywhere
+    dst = SwinUPerNet("swin_tiny_patch4_window7_224", 3, 19, 128)   # last stage map 4 -> window 4, table 49 x 24
+    sd = {"model." + k.replace("layers_", "layers."): v.clone() for k, v in src.state_dict().items()}
+    path = str(tmp_path / "ckpt.safetensors")
+    save_file(sd, path)
+    conf = {"paths": {"ckpt_model_path": path}, "labels": [], "labels_configs": {}}
+    load_checkpoint(conf, dst)
+    key = "encoder.model.layers_3.blocks.0.attn.relative_position_bias_table"
+    a, b = src.state_dict()[key], dst.state_dict()[key]
+    assert a.shape == (169, 24) and b.shape == (49, 24)
+    assert torch.equal(b, interpolate_bias_table(a, b))
+    k2 = "encoder.model.layers_1.blocks.0.attn.qkv.weight"
+    assert torch.equal(src.state_dict()[k2], dst.state_dict()[k2])

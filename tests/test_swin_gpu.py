@@ -260,3 +260,101 @@ def test_swin_state_dict_accepts_timm_spelling_and_training_refuses():
     m2 = m2.to(DEV).train()
     with pytest.raises(NotImplementedError):
         m2.encoder(torch.zeros(1, 64, 64, 16, device=DEV, dtype=torch.bfloat16))
+
+
+# ---------------------------------------------------------------------------------------------------- FLAIR_HUB_Model glue
+
+def _flair_swin(precision, sizes):
+    from flairhip.configs import fusion_unet_config
+    from flair_hub.tasks.module_setup import build_segmentation_module
+    from oracle.seeded_weights import fill_swin_state_dict
+    cfg = fusion_unet_config(precision=precision)
+    cfg["models"]["monotemp_model"]["arch"] = "swin_tiny_patch4_window7_224-upernet"
+    task = build_segmentation_module(cfg, sizes, "train")
+    task.model.load_state_dict(fill_swin_state_dict(task.model.state_dict()))
+    return task.cuda().eval(), cfg
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_two_swin_encoders_fused_match_the_reference_model(precision):
+    """tests/golden/swin_two_mod.npz: the REFERENCE's FLAIR_HUB_Model (two Swin-T encoders, FusionHandler's
+    placeholder-stage stripping, UPerNet task decoders + auxiliary decoder) on the same seeded weights and inputs"""
+    import json
+    import os
+    import numpy as np
+    from helpers import MOD, ROOT, TASK
+    gold = os.path.join(ROOT, "tests", "golden")
+    d = np.load(os.path.join(gold, "swin_two_mod.npz"))
+    info = json.load(open(os.path.join(gold, "swin_two_mod.json")))
+    task, cfg = _flair_swin(precision, {MOD: 96, "DEM_ELEV": 64})
+    assert sorted(task.model.state_dict().keys()) == info["state_dict_keys"]
+    assert list(task.model.encoders[MOD].seg_model.out_channels) == info["encoder_out_channels"]
+    batch = {MOD: torch.from_numpy(d["x_aerial"]).cuda(), "DEM_ELEV": torch.from_numpy(d["x_dem"]).cuda(),
+             TASK: torch.zeros(2, 19, 96, 96, device=DEV), "ALL_LABEL-LPIS": torch.zeros(2, 96, 96, dtype=torch.long, device=DEV)}
+    with torch.no_grad():
+        lt, la = task.model(batch)
+    assert sorted(lt.keys()) == info["logit_keys"] and sorted(la.keys()) == info["aux_keys"]
+    pairs = [(lt[TASK], d["logits_cosia"]), (lt["ALL_LABEL-LPIS"][:1], d["logits_lpis"]),
+             (la["aux_AERIAL_RGBI_" + TASK][:1], d["logits_aux_cosia"])]
+    for got, ref in pairs:
+        got = got.float().cpu().numpy()
+        assert got.shape == ref.shape
+        if precision == "fp32":
+            assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+        else:
+            assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 4e-2
+            assert (got.argmax(1) == ref.argmax(1)).mean() >= 0.97
+
+
+# ---------------------------------------------------------------------------------------------------- zonal loop
+
+@pytest.mark.parametrize("output_type,precision", [("argmax", "fp32"), ("class_prob", "fp32"), ("argmax", "bf16")])
+def test_zonal_run_with_swin_upernet_matches_the_oracle_loop(tmp_path, output_type, precision):
+    """the fork's live configuration (configs/config_model_zonal_segmentation.yaml:26: a Swin + UPerNet checkpoint on
+    RGB tiles) through run_inference, against the reference's tile loop restated around the CPU oracle network"""
+    import os
+    import numpy as np
+    import yaml
+    from helpers import MOD, ROOT, TASK, oracle_to_product_keys
+    from flair_zonal_detection.inference import run_inference
+    from flair_zonal_detection.raster import ArrayRaster
+    from oracle.seeded_weights import fill_swin_state_dict
+    from oracle.swin_upernet import SwinUPerNet as OracleNet
+    from oracle.tile_bookkeeping import convert as o_convert, slice_tiles, write_window
+    H, W, patch, margin, res = 300, 410, 128, 16, 0.2
+    g = np.random.default_rng(3)
+    img = g.integers(0, 255, (3, H, W)).astype(np.uint8)
+    ras = ArrayRaster(img, 651992.36, 6860417.84, res)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "tests", "golden", "zonal_config.yaml")))
+    means, stds = [105.66, 111.35, 102.18], [52.23, 45.62, 44.30]
+    cfg.update({"output_path": str(tmp_path), "output_name": "z", "img_pixels_detection": patch, "margin": margin,
+                "output_px_meters": res, "output_type": output_type, "batch_size": 4, "num_worker": 0,
+                "monotemp_arch": "swin_tiny_patch4_window7_224-upernet", "hardware": {"precision": precision}})
+    cfg["modalities"][MOD].update({"input_img_path": ras, "channels": [1, 2, 3],
+                                   "normalization": {"type": "custom", "means": means, "stds": stds}})
+    cfg["tasks"] = [{"name": TASK, "active": True, "class_names": {i: f"c{i}" for i in range(19)}}]
+    oracle = OracleNet("swin_tiny_patch4_window7_224", 3, 19, patch).eval()
+    oracle.load_state_dict(fill_swin_state_dict(oracle.state_dict(), seed=77))
+    ckpt = {"state_dict": {"model." + k: v for k, v in oracle_to_product_keys(oracle.state_dict()).items()}}
+    cfg["model_weights"] = str(tmp_path / "w.ckpt")
+    torch.save(ckpt, cfg["model_weights"])
+    got = run_inference(cfg)[TASK].data
+
+    bounds = tuple(ras.bounds)
+    canvas = np.zeros_like(got)
+    for t in slice_tiles(bounds, bounds, patch, margin, res):
+        x = ras.read_bounds([1, 2, 3], t["box"], patch).astype(np.float64)
+        for c in range(3):
+            x[c] = (x[c] - means[c]) / stds[c]
+        with torch.no_grad():
+            logits = oracle(torch.tensor(x[None], dtype=torch.float32))[0].numpy()
+        p = o_convert(logits[:, margin:patch - margin, margin:patch - margin], output_type)
+        col, row, w, h, skip = write_window(t["left"], t["top"], bounds, res, p.shape[-2], p.shape[-1])
+        if skip:
+            continue
+        canvas[:, row:row + h, col:col + w] = p[:, :h, :w]
+    if output_type == "argmax":
+        assert (got == canvas).mean() >= (0.9995 if precision == "fp32" else 0.97)
+    else:
+        assert np.abs(got.astype(int) - canvas.astype(int)).max() <= 1
+    assert got.any()
