@@ -36,7 +36,15 @@ constexpr int GIMG = (GBM + GBN) * GPITCH;        // one LDS image
 constexpr int GEP = 144;                          // epilogue row pitch (64 features bf16 + pad)
 }  // namespace
 
-__device__ __forceinline__ float gemm_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// nn.GELU() (erf form) for the bf16 epilogue: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16's
+// 2^-9), one v_exp + one v_rcp instead of libm's branchy erff -- which cost as much as the fc1 GEMM's whole main loop
+__device__ __forceinline__ float gemm_gelu(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 
 __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GIMG];

@@ -67,77 +67,113 @@ extern "C" int ffa_space_to_depth(int dtype, const void* in, void* out, int B, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm over the last dimension, one wave per row.  merge = 1: the row is PatchMerging's gather
-// (timm swin_transformer.py PatchMerging.forward: reshape(B, H/2, 2, W/2, 2, C).permute(0, 1, 3, 4, 2, 5).flatten(3)):
+// LayerNorm over the last dimension.  A row is shared by LPR lanes (16 / 32 / 64: the smallest power of two covering
+// its C / 8 sixteen-byte pieces, so a 128-channel row keeps 16 lanes busy and a wave normalises four rows at once); each
+// lane keeps its GPL pieces in registers: one read and one write of the tensor.  Mean first, then the variance of the
+// centred values (the two-pass form nn.LayerNorm's f32 kernel is equivalent to), reduced by xor-shuffles inside the group.
+// MERGE: the row is PatchMerging's gather (timm swin_transformer.py PatchMerging.forward:
+// reshape(B, H/2, 2, W/2, 2, C).permute(0, 1, 3, 4, 2, 5).flatten(3)):
 // row (b, y, x) of width 4C = [ x(2y, 2x) | x(2y+1, 2x) | x(2y, 2x+1) | x(2y+1, 2x+1) ]; Ho / Wo are the merged sizes.
-// Mean first, then the variance of the centred values (the two-pass form nn.LayerNorm's f32 kernel is equivalent to).
 
-template <typename T, bool MERGE>
+template <typename T, bool MERGE, int LPR, int GPL>
 __global__ void __launch_bounds__(256) layer_norm_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, long long rows, int C, int Ho,
                                                          int Wo, float eps) {
-  const int lane = threadIdx.x & 63;
-  const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int CG = C / 8;  // output row width in 8-channel groups
+  constexpr int RPB = 256 / LPR;  // rows per block
+  const int sub = threadIdx.x % LPR;
+  const long long row = blockIdx.x * (long long)RPB + threadIdx.x / LPR;
+  const bool live = row < rows;
+  const int CG = C / 8;  // output row width in 16-byte pieces
   const int Cs = MERGE ? C / 4 : C;
   const int CGs = Cs / 8;
-  long long base[4];
-  if (MERGE) {
-    const int xo = (int)(row % Wo);
-    const long long t = row / Wo;
-    const int yo = (int)(t % Ho);
-    const long long b = t / Ho;
+  long long base[4] = {0, 0, 0, 0};
+  if (live) {
+    if (MERGE) {
+      const int xo = (int)(row % Wo);
+      const long long t = row / Wo;
+      const int yo = (int)(t % Ho);
+      const long long b = t / Ho;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-      base[s] = ((b * (2 * Ho) + 2 * yo + (s & 1)) * (2LL * Wo) + 2 * xo + (s >> 1)) * Cs;
-  } else {
-    base[0] = row * (long long)C;
-  }
-  auto src = [&](int g) -> const T* {
-    if (MERGE) return x + base[g / CGs] + (g % CGs) * 8;
-    return x + base[0] + g * 8;
-  };
-  float sum = 0.f;
-  for (int g = lane; g < CG; g += 64) {
-    float v[8];
-    ffa_load8<T>(src(g), v);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) sum += v[e];
-  }
-  const float mean = ffa_wave_sum(sum) / (float)C;
-  float sq = 0.f;
-  for (int g = lane; g < CG; g += 64) {
-    float v[8];
-    ffa_load8<T>(src(g), v);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float d = v[e] - mean;
-      sq += d * d;
+      for (int s = 0; s < 4; ++s)
+        base[s] = ((b * (2 * Ho) + 2 * yo + (s & 1)) * (2LL * Wo) + 2 * xo + (s >> 1)) * Cs;
+    } else {
+      base[0] = row * (long long)C;
     }
   }
-  const float rstd = 1.0f / sqrtf(ffa_wave_sum(sq) / (float)C + eps);
-  for (int g = lane; g < CG; g += 64) {
-    float v[8], o[8];
-    ffa_load8<T>(src(g), v);
+  float v[GPL][8];
+  float sum = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (v[e] - mean) * rstd * gamma[g * 8 + e] + beta[g * 8 + e];
-    ffa_store8<T>(y + row * (long long)C + g * 8, o);
+  for (int j = 0; j < GPL; ++j) {
+    const int g = sub + LPR * j;
+    if (live && g < CG) {
+      const T* src = MERGE ? x + base[g / CGs] + (g % CGs) * 8 : x + base[0] + g * 8;
+      ffa_load8<T>(src, v[j]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += v[j][e];
   }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < GPL; ++j) {
+    if (sub + LPR * j < CG) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[j][e] - mean;
+        sq += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+  if (!live) return;
+#pragma unroll
+  for (int j = 0; j < GPL; ++j) {
+    const int g = sub + LPR * j;
+    if (g < CG) {
+      float ga[8], be[8], o[8];
+      ffa_load8<float>(gamma + g * 8, ga);
+      ffa_load8<float>(beta + g * 8, be);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[j][e] - mean) * rstd * ga[e] + be[e];
+      ffa_store8<T>(y + row * (long long)C + g * 8, o);
+    }
+  }
+}
+
+template <typename T, bool MERGE>
+static int layer_norm_launch(const void* x, void* y, const float* gamma, const float* beta, long long rows, int C, int Ho,
+                             int Wo, float eps, hipStream_t stream) {
+  const int CG = C / 8;
+#define FFA_LN_CASE(LPR, GPL)                                                                                        \
+  hipLaunchKernelGGL((layer_norm_kernel<T, MERGE, LPR, GPL>), dim3((unsigned)((rows + 256 / LPR - 1) / (256 / LPR))), \
+                     dim3(256), 0, stream, (const T*)x, (T*)y, gamma, beta, rows, C, Ho, Wo, eps)
+  if (CG <= 16) FFA_LN_CASE(16, 1);
+  else if (CG <= 32) FFA_LN_CASE(32, 1);
+  else if (CG <= 64) FFA_LN_CASE(64, 1);
+  else if (CG <= 128) FFA_LN_CASE(64, 2);
+  else if (CG <= 256) FFA_LN_CASE(64, 4);
+  else if (CG <= 512) FFA_LN_CASE(64, 8);
+  else {
+    ffa_set_error("layer_norm: C = %d exceeds 4096", C);
+    return FFA_ERR_UNSUPPORTED;
+  }
+#undef FFA_LN_CASE
+  return ffa_check_launch(MERGE ? "patch_merge_norm" : "layer_norm");
 }
 
 extern "C" int ffa_layer_norm(int dtype, const void* x, void* y, const float* gamma, const float* beta, long long rows,
                               int C, float eps, hipStream_t stream) {
   FFA_REQUIRE(x && y && gamma && beta && rows > 0 && C > 0 && C % 8 == 0, "layer_norm: bad arguments");
-  const dim3 grid((unsigned)((rows + 3) / 4));
-  if (dtype == FFA_BF16)
-    hipLaunchKernelGGL((layer_norm_kernel<ffa_bf16, false>), grid, dim3(256), 0, stream, (const ffa_bf16*)x,
-                       (ffa_bf16*)y, gamma, beta, rows, C, 0, 0, eps);
-  else
-    hipLaunchKernelGGL((layer_norm_kernel<float, false>), grid, dim3(256), 0, stream, (const float*)x, (float*)y, gamma,
-                       beta, rows, C, 0, 0, eps);
-  return ffa_check_launch("layer_norm");
+  if (dtype == FFA_BF16) return layer_norm_launch<ffa_bf16, false>(x, y, gamma, beta, rows, C, 0, 0, eps, stream);
+  return layer_norm_launch<float, false>(x, y, gamma, beta, rows, C, 0, 0, eps, stream);
 }
 
 extern "C" int ffa_patch_merge_norm(int dtype, const void* x, void* y, const float* gamma, const float* beta, int B,
@@ -145,14 +181,9 @@ extern "C" int ffa_patch_merge_norm(int dtype, const void* x, void* y, const flo
   FFA_REQUIRE(x && y && gamma && beta && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "patch_merge_norm: bad arguments");
   FFA_REQUIRE(H % 2 == 0 && W % 2 == 0, "patch_merge_norm: odd map %d x %d (the padded variant is not implemented)", H, W);
   const long long rows = (long long)B * (H / 2) * (W / 2);
-  const dim3 grid((unsigned)((rows + 3) / 4));
   if (dtype == FFA_BF16)
-    hipLaunchKernelGGL((layer_norm_kernel<ffa_bf16, true>), grid, dim3(256), 0, stream, (const ffa_bf16*)x, (ffa_bf16*)y,
-                       gamma, beta, rows, 4 * C, H / 2, W / 2, eps);
-  else
-    hipLaunchKernelGGL((layer_norm_kernel<float, true>), grid, dim3(256), 0, stream, (const float*)x, (float*)y, gamma,
-                       beta, rows, 4 * C, H / 2, W / 2, eps);
-  return ffa_check_launch("patch_merge_norm");
+    return layer_norm_launch<ffa_bf16, true>(x, y, gamma, beta, rows, 4 * C, H / 2, W / 2, eps, stream);
+  return layer_norm_launch<float, true>(x, y, gamma, beta, rows, 4 * C, H / 2, W / 2, eps, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -314,24 +345,28 @@ __global__ void __launch_bounds__(256) window_attention_f32_kernel(WinAttnArgs a
   }
 }
 
-// ---- bf16 path: MFMA 16x16x32.  Per (window, head) block: q / k [NP][32] bf16 at an 80-byte row pitch (conflict-free
-// 16-byte fragment reads), v transposed + key-permuted [32][NP] so that one 16-byte read is a lane's A fragment.
-// S^T = K Q^T per 16-query tile (lane: query n = lane % 16, keys 16 t + 4 (lane / 16) + i), softmax across the four
-// lane groups of a query by two xor-shuffles, then O^T = V^T P^T with P^T taken straight from the S^T registers: the
-// k-slot order of a 32-key MFMA block is [tile 2u keys 4g..4g+3 | tile 2u+1 keys 4g..4g+3] for lane group g, and V^T is
-// stored in LDS in exactly that order.
-template <int NTP>  // padded key tiles of 16 (even): 4 (ws <= 8) or 10 (ws <= 12)
-__global__ void __launch_bounds__(256) window_attention_bf16_kernel(WinAttnArgs a) {
+// ---- bf16 path: MFMA 16x16x32.  One block per (window, head), NW waves, each wave takes 16-query tiles round-robin.
+// LDS holds only what the waves share: k [NP][32] bf16 at an 80-byte row pitch (conflict-free 16-byte fragment reads),
+// v row-major [NP][32] at a 96-byte pitch (conflict-free ds_read_b64_tr_b16 transposed reads), one packed word per key
+// (relative-position line index | region id << 16) and the head's bias table.  A lane's q fragment comes straight from
+// global memory.  S^T = K Q^T per tile (lane: query n = lane % 16, keys 16 t + 4 (lane / 16) + i), softmax across the
+// four lane groups of a query by two xor-shuffles, then O^T = V^T P^T with P^T taken straight from the S^T registers:
+// the k-slot order of a 32-key MFMA block is [tile 2u keys 4g..4g+3 | tile 2u+1 keys 4g..4g+3] for lane group g, which
+// is what two transposed reads of V (4 keys x 16 channels each) deliver.
+__device__ __forceinline__ ffa_s16x4 attn_read_tr16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) ffa_s16x4*)(const_cast<unsigned char*>(p)));
+}
+
+template <int NTP, int NW>  // padded key tiles of 16 (even): 4 (ws <= 8) or 10 (ws <= 12); waves per block
+__global__ void __launch_bounds__(64 * NW) window_attention_bf16_kernel(WinAttnArgs a) {
   constexpr int NP = NTP * 16;
-  constexpr int QP = 80;             // q / k row pitch in bytes
-  constexpr int VP = NP * 2 + 16;    // v^T row pitch in bytes (one row per head channel)
-  __shared__ __attribute__((aligned(16))) unsigned char sq[NP * QP];
-  __shared__ __attribute__((aligned(16))) unsigned char sk[NP * QP];
-  __shared__ __attribute__((aligned(16))) unsigned char svt[32 * VP];
+  constexpr int KP = 80;  // k row pitch in bytes
+  constexpr int VP = 96;  // v row pitch in bytes
+  __shared__ __attribute__((aligned(16))) unsigned char sk[NP * KP];
+  __shared__ __attribute__((aligned(16))) unsigned char sv[NP * VP];
+  __shared__ __attribute__((aligned(16))) int skey[NP];
   __shared__ float stab[23 * 23];
-  __shared__ short slin[NP];
-  __shared__ short srid[NP];
-  __shared__ long long soff[NP];
   const int N = a.ws * a.ws;
   const int head = blockIdx.y;
   int w = blockIdx.x;
@@ -341,51 +376,41 @@ __global__ void __launch_bounds__(256) window_attention_bf16_kernel(WinAttnArgs 
   const int b = w / a.nwy;
   const ffa_bf16* qkv = (const ffa_bf16*)a.qkv;
   const int C3 = 3 * a.C;
-  for (int i = threadIdx.x; i < NP; i += blockDim.x) {
-    if (i < N) {
-      const WinTok tk = win_token(a, b, wy, wx, i);
-      slin[i] = (short)tk.lin;
-      srid[i] = (short)tk.rid;
-      soff[i] = tk.off;
-    } else {
-      slin[i] = 0;
-      srid[i] = -1;  // padded key: excluded from the softmax
-      soff[i] = -1;
-    }
-  }
   const int TS = (2 * a.ws - 1) * (2 * a.ws - 1);
-  for (int i = threadIdx.x; i < TS; i += blockDim.x) stab[i] = a.table[i * a.heads + head];
-  __syncthreads();
-  // stage q, k (row-major) and v (transposed, key-permuted); 4 pieces of 8 channels per token and operand
-  for (int i = threadIdx.x; i < NP * 4; i += blockDim.x) {
+  // everything in log2 units: softmax(x) = 2^(x log2e - max) / sum, one v_exp_f32 per element and no multiply
+  constexpr float LOG2E = 1.4426950408889634f;
+  for (int i = threadIdx.x; i < TS; i += 64 * NW) stab[i] = a.table[i * a.heads + head] * LOG2E;
+  const float scale2 = a.scale * LOG2E;
+  // only the windows of the last window row / column hold more than one region of the shifted-window mask
+  const bool masked = a.shift > 0 && (wy == a.nwy - 1 || wx == a.nwx - 1);
+  // stage k and v: 4 pieces of 8 channels per key and operand; keys past the window are zero and flagged
+  for (int i = threadIdx.x; i < NP * 4; i += 64 * NW) {
     const int t = i >> 2, pc = i & 3;
-    const long long off = soff[t];
     const int c = head * 32 + pc * 8;
-    float q[8], k[8], v[8];
-    if (t >= N) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) q[e] = k[e] = v[e] = 0.f;
-    } else if (off >= 0) {
-      const ffa_bf16* p = qkv + off * C3 + c;
-      ffa_load8<ffa_bf16>(p, q);
-      ffa_load8<ffa_bf16>(p + a.C, k);
-      ffa_load8<ffa_bf16>(p + 2 * a.C, v);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
+    ffa_u32x4 k4 = {0u, 0u, 0u, 0u}, v4 = {0u, 0u, 0u, 0u};
+    int packed = 0xffff0000;  // region id -1: excluded from the softmax
+    if (t < N) {
+      const WinTok tk = win_token(a, b, wy, wx, t);
+      packed = tk.lin | (tk.rid << 16);
+      if (tk.off >= 0) {
+        const ffa_bf16* p = qkv + tk.off * C3 + a.C + c;
+        k4 = *reinterpret_cast<const ffa_u32x4*>(p);
+        v4 = *reinterpret_cast<const ffa_u32x4*>(p + a.C);
+      } else {
         // a padding token's projection is the bias itself, rounded like every other element of the qkv tensor
-        q[e] = ffa_bf16_bits_to_f32(ffa_f32_to_bf16_bits(a.qkv_bias[c + e]));
-        k[e] = ffa_bf16_bits_to_f32(ffa_f32_to_bf16_bits(a.qkv_bias[a.C + c + e]));
-        v[e] = ffa_bf16_bits_to_f32(ffa_f32_to_bf16_bits(a.qkv_bias[2 * a.C + c + e]));
+        float kf[8], vf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          kf[e] = a.qkv_bias[a.C + c + e];
+          vf[e] = a.qkv_bias[2 * a.C + c + e];
+        }
+        ffa_store8<ffa_bf16>(reinterpret_cast<ffa_bf16*>(&k4), kf);
+        ffa_store8<ffa_bf16>(reinterpret_cast<ffa_bf16*>(&v4), vf);
       }
     }
-    ffa_store8<ffa_bf16>(reinterpret_cast<ffa_bf16*>(sq + t * QP + pc * 16), q);
-    ffa_store8<ffa_bf16>(reinterpret_cast<ffa_bf16*>(sk + t * QP + pc * 16), k);
-    // key t = 32 u + 16 h + 4 g + j  ->  slot 32 u + 8 g + 4 h + j
-    const int slot = (t & ~31) | (((t >> 2) & 3) << 3) | (((t >> 4) & 1) << 2) | (t & 3);
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      *reinterpret_cast<uint16_t*>(svt + (pc * 8 + e) * VP + slot * 2) = ffa_f32_to_bf16_bits(v[e]);
+    *reinterpret_cast<ffa_u32x4*>(sk + t * KP + pc * 16) = k4;
+    *reinterpret_cast<ffa_u32x4*>(sv + t * VP + pc * 16) = v4;
+    if (pc == 0) skey[t] = packed;
   }
   __syncthreads();
 
@@ -393,24 +418,51 @@ __global__ void __launch_bounds__(256) window_attention_bf16_kernel(WinAttnArgs 
   const int n = lane & 15, g = lane >> 4;
   const int off0 = (a.ws - 1) * (2 * a.ws - 1) + (a.ws - 1);
   const int nqt = (N + 15) / 16;
-  for (int qt = wave; qt < nqt; qt += 4) {
+  // transposed-read address of this lane inside a 4-key x 16-channel block: row (lane / 4) % 4, channels 4 (lane % 4)
+  const int tr_off = ((lane >> 2) & 3) * VP + (lane & 3) * 8;
+  for (int qt = wave; qt < nqt; qt += NW) {  // wave-uniform trip count: EXEC stays full for the transposed reads
     const int qi = qt * 16 + n;  // this lane's query (may be >= N: computed, never stored)
-    const ffa_bf16x8 qf = *reinterpret_cast<const ffa_bf16x8*>(sq + qi * QP + g * 16);
-    const int qlin = slin[qi] + off0, qrid = srid[qi];
+    long long qoff = -1;
+    int qlin = off0, qrid = -2;
+    ffa_bf16x8 qf;
+    {
+      ffa_u32x4 q4 = {0u, 0u, 0u, 0u};
+      if (qi < N) {
+        const WinTok tk = win_token(a, b, wy, wx, qi);
+        qlin += tk.lin;
+        qrid = tk.rid;
+        qoff = tk.off;
+        if (qoff >= 0) {
+          q4 = *reinterpret_cast<const ffa_u32x4*>(qkv + qoff * C3 + head * 32 + g * 8);
+        } else {
+          float qv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) qv[e] = a.qkv_bias[head * 32 + g * 8 + e];
+          ffa_store8<ffa_bf16>(reinterpret_cast<ffa_bf16*>(&q4), qv);
+        }
+      }
+      qf = __builtin_bit_cast(ffa_bf16x8, q4);
+    }
     ffa_f32x4 s[NTP];
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < NTP; ++t) {
-      const ffa_bf16x8 kf = *reinterpret_cast<const ffa_bf16x8*>(sk + (t * 16 + n) * QP + g * 16);
+      if (t >= nqt) {  // a tile of padding keys only (block-uniform): probability 0, no work
+        s[t] = ffa_f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        continue;
+      }
+      const ffa_bf16x8 kf = *reinterpret_cast<const ffa_bf16x8*>(sk + (t * 16 + n) * KP + g * 16);
+      const int4 key4 = *reinterpret_cast<const int4*>(&skey[t * 16 + g * 4]);
       ffa_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, acc, 0, 0, 0);
+      const int kk[4] = {key4.x, key4.y, key4.z, key4.w};
+      const bool ragged = (t + 1) * 16 > N;  // the one tile that mixes keys and padding (block-uniform)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int kj = t * 16 + g * 4 + i;
-        const int krid = srid[kj];
-        float v = acc[i] * a.scale + stab[qlin - slin[kj]];
-        if (krid != qrid) v += -100.0f;
-        if (krid < 0) v = -INFINITY;
+        const int klin = kk[i] & 0xffff;
+        float v = acc[i] * scale2 + stab[qlin - klin];
+        if (masked && (kk[i] >> 16) != qrid) v += -100.0f * LOG2E;
+        if (ragged && kk[i] < 0) v = -INFINITY;
         acc[i] = v;
         mx = fmaxf(mx, v);
       }
@@ -420,13 +472,18 @@ __global__ void __launch_bounds__(256) window_attention_bf16_kernel(WinAttnArgs 
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
 #pragma unroll
-    for (int t = 0; t < NTP; ++t)
+    for (int t = 0; t < NTP; ++t) {
+      if (t >= nqt) {
+        s[t] = ffa_f32x4{0.f, 0.f, 0.f, 0.f};
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float e = __expf(s[t][i] - mx);
+        const float e = __builtin_amdgcn_exp2f(s[t][i] - mx);
         s[t][i] = e;
         sum += e;
       }
+    }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     ffa_f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
@@ -438,25 +495,31 @@ __global__ void __launch_bounds__(256) window_attention_bf16_kernel(WinAttnArgs 
         pf[i] = (__bf16)s[2 * u][i];
         pf[4 + i] = (__bf16)s[2 * u + 1][i];
       }
-      const ffa_bf16x8 v0 = *reinterpret_cast<const ffa_bf16x8*>(svt + n * VP + (u * 32 + g * 8) * 2);
-      const ffa_bf16x8 v1 = *reinterpret_cast<const ffa_bf16x8*>(svt + (16 + n) * VP + (u * 32 + g * 8) * 2);
-      o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pf, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, pf, o1, 0, 0, 0);
+      // lane group g: keys 32u + 4g .. +3 (tile 2u) and 32u + 16 + 4g .. +3 (tile 2u + 1), channels 0-15 / 16-31
+      const unsigned char* vb = sv + (u * 32 + g * 4) * VP + tr_off;
+      const ffa_s16x4 a00 = attn_read_tr16(vb);
+      const ffa_s16x4 a01 = attn_read_tr16(vb + 16 * VP);
+      const ffa_s16x4 a10 = attn_read_tr16(vb + 32);
+      const ffa_s16x4 a11 = attn_read_tr16(vb + 16 * VP + 32);
+      ffa_u32x4 v0, v1;
+      v0.x = __builtin_bit_cast(ffa_u32x2, a00).x; v0.y = __builtin_bit_cast(ffa_u32x2, a00).y;
+      v0.z = __builtin_bit_cast(ffa_u32x2, a01).x; v0.w = __builtin_bit_cast(ffa_u32x2, a01).y;
+      v1.x = __builtin_bit_cast(ffa_u32x2, a10).x; v1.y = __builtin_bit_cast(ffa_u32x2, a10).y;
+      v1.z = __builtin_bit_cast(ffa_u32x2, a11).x; v1.w = __builtin_bit_cast(ffa_u32x2, a11).y;
+      o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ffa_bf16x8, v0), pf, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ffa_bf16x8, v1), pf, o1, 0, 0, 0);
     }
     // lane: query n, channels 4g..4g+3 (o0) and 16+4g..16+4g+3 (o1)
-    if (qi < N) {
-      const long long off = soff[qi];
-      if (off >= 0) {
-        const float inv = 1.0f / sum;
-        ffa_bf16* dst = (ffa_bf16*)a.out + off * a.C + head * 32 + g * 4;
-        uint2 lo, hi;
-        lo.x = ffa_pack_bf16x2(o0[0] * inv, o0[1] * inv);
-        lo.y = ffa_pack_bf16x2(o0[2] * inv, o0[3] * inv);
-        hi.x = ffa_pack_bf16x2(o1[0] * inv, o1[1] * inv);
-        hi.y = ffa_pack_bf16x2(o1[2] * inv, o1[3] * inv);
-        *reinterpret_cast<uint2*>(dst) = lo;
-        *reinterpret_cast<uint2*>(dst + 16) = hi;
-      }
+    if (qoff >= 0) {
+      const float inv = 1.0f / sum;
+      ffa_bf16* dst = (ffa_bf16*)a.out + qoff * a.C + head * 32 + g * 4;
+      uint2 lo, hi;
+      lo.x = ffa_pack_bf16x2(o0[0] * inv, o0[1] * inv);
+      lo.y = ffa_pack_bf16x2(o0[2] * inv, o0[3] * inv);
+      hi.x = ffa_pack_bf16x2(o1[0] * inv, o1[1] * inv);
+      hi.y = ffa_pack_bf16x2(o1[2] * inv, o1[3] * inv);
+      *reinterpret_cast<uint2*>(dst) = lo;
+      *reinterpret_cast<uint2*>(dst + 16) = hi;
     }
   }
 }
@@ -482,9 +545,9 @@ extern "C" int ffa_window_attention(int dtype, const void* qkv, void* out, const
   const int N = ws * ws;
   if (dtype == FFA_BF16) {
     if (N <= 64)
-      hipLaunchKernelGGL(window_attention_bf16_kernel<4>, grid, dim3(256), 0, stream, a);
+      hipLaunchKernelGGL((window_attention_bf16_kernel<4, 4>), grid, dim3(256), 0, stream, a);
     else
-      hipLaunchKernelGGL(window_attention_bf16_kernel<10>, grid, dim3(256), 0, stream, a);
+      hipLaunchKernelGGL((window_attention_bf16_kernel<10, 3>), grid, dim3(192), 0, stream, a);
   } else {
     const int TS = (2 * ws - 1) * (2 * ws - 1);
     const size_t lds = (size_t)(3 * N * 33 + 4 * N + TS) * 4 + (size_t)(2 * N + (N & 1)) * 4 + (size_t)N * 8 + 16;

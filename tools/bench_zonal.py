@@ -31,6 +31,11 @@ def main():
     ap.add_argument("--output-type", default="argmax", choices=["argmax", "class_prob"])
     ap.add_argument("--profile", action="store_true", help="cProfile of the tile loop (host hot spots)")
     ap.add_argument("--tif", action="store_true", help="also run from / to GeoTIFF files (built-in reader / writer)")
+    ap.add_argument("--arch", default="resnet34-unet",
+                    help="models.monotemp_model.arch, e.g. swin_base_patch4_window12_384-upernet (the fork's zonal config)")
+    ap.add_argument("--channels", type=int, default=5)
+    ap.add_argument("--forward-only", action="store_true", help="skip the tile loop (kernel profiles of the network)")
+    ap.add_argument("--iters", type=int, default=10)
     args = ap.parse_args()
     from flairhip.configs import unet_resnet34_config
     from flair_hub.models.flair_model import FLAIR_HUB_Model
@@ -40,35 +45,39 @@ def main():
     dev = torch.device("cuda:0")
     MOD, TASK = "AERIAL_RGBI", "AERIAL_LABEL-COSIA"
     # (a) forward alone
-    cfg = unet_resnet34_config(in_channels=5, precision=args.precision)
+    C = args.channels
+    cfg = unet_resnet34_config(in_channels=C, precision=args.precision)
+    cfg["models"]["monotemp_model"]["arch"] = args.arch
     model = FLAIR_HUB_Model(cfg, {MOD: 512}).to(dev).eval()
     for B in (args.batch, 32):
-        x = torch.randn(B, 5, 512, 512, device=dev)
+        x = torch.randn(B, C, 512, 512, device=dev)
         with torch.no_grad():
             for _ in range(3):
                 model({MOD: x})
             torch.cuda.synchronize()
             t0 = time.time()
-            n = 10
+            n = args.iters
             for _ in range(n):
                 model({MOD: x})
             torch.cuda.synchronize()
         dt = (time.time() - t0) / n
         print(f"forward only, batch {B:2d}: {dt * 1e3:7.2f} ms/batch = {B / dt:8.1f} tiles/s")
 
+    if args.forward_only:
+        return
     # (b) the zonal loop
     g = np.random.default_rng(0)
     H = W = args.size
-    img = g.integers(0, 255, (5, H, W), dtype=np.uint8)
+    img = g.integers(0, 255, (C, H, W), dtype=np.uint8)
     ras = ArrayRaster(img, 651000.0, 6865000.0, 0.2)
     zc = yaml.safe_load(open(os.path.join(ROOT, "tests", "golden", "zonal_config.yaml")))
     zc.update({"output_path": "/tmp", "output_name": "bench_zonal", "img_pixels_detection": 512, "margin": 40,
                "output_px_meters": 0.2, "output_type": args.output_type, "batch_size": args.batch, "num_worker": 0,
                "hardware": {"precision": args.precision}, "model_weights": "/tmp/bench_zonal_weights.ckpt",
-               "monotemp_arch": "resnet34-unet"})
+               "monotemp_arch": args.arch})
     torch.save({"state_dict": {"model." + k: v.cpu() for k, v in model.state_dict().items()}}, zc["model_weights"])
-    zc["modalities"][MOD].update({"input_img_path": ras, "channels": [1, 2, 3, 4, 5],
-                                  "normalization": {"type": "custom", "means": [110.0] * 5, "stds": [50.0] * 5}})
+    zc["modalities"][MOD].update({"input_img_path": ras, "channels": list(range(1, C + 1)),
+                                  "normalization": {"type": "custom", "means": [110.0] * C, "stds": [50.0] * C}})
     zc["tasks"] = [{"name": TASK, "active": True, "class_names": {i: f"c{i}" for i in range(19)}}]
     t0 = time.time()
     out = run_inference(zc)
