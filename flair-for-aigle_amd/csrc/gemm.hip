@@ -18,6 +18,7 @@
 
 #define FFA_ACT_NONE 0
 #define FFA_ACT_GELU 1
+#define FFA_ACT_DGELU 2  // out = acc * gelu'(aux): the input gradient of fc2 carried through Mlp's activation
 
 struct GemmArgs {
   const ffa_bf16* a;
@@ -25,8 +26,10 @@ struct GemmArgs {
   const float* bias;
   const ffa_bf16* residual;
   ffa_bf16* out;
-  long long lda, ldr, ldc;
-  int M, K, N, act, nblk_n;
+  ffa_bf16* aux;           // GELU: the pre-activation is stored here as well (training); DGELU: read from here
+  const float* row_scale;  // optional per-sample factor (DropPath): rows [i * rows_per_scale, (i+1) * rows_per_scale)
+  long long lda, ldr, ldc, ldaux;
+  int M, K, N, act, nblk_n, rows_per_scale;
 };
 
 namespace {
@@ -44,6 +47,15 @@ __device__ __forceinline__ float gemm_gelu(float x) {
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float erf_abs = 1.0f - poly * __expf(-z * z);
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+// d/dx gelu(x) = Phi(x) + x phi(x)
+__device__ __forceinline__ float gemm_dgelu(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float ex = __expf(-z * z);  // exp(-x^2 / 2)
+  const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * ex, x));
+  return cdf + x * ex * 0.39894228040143267794f;
 }
 
 __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs g) {
@@ -151,7 +163,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v[e] = acc[i][j][e] + b4[e];
-        if (g.act == FFA_ACT_GELU) v[e] = gemm_gelu(v[e]);
+        if (g.act == FFA_ACT_GELU && !g.aux) v[e] = gemm_gelu(v[e]);
       }
       uint2 pk;
       pk.x = ffa_pack_bf16x2(v[0], v[1]);
@@ -169,12 +181,32 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs g) {
     const int row = m0 + wm * 64 + t;
     if (row < g.M && col < g.N) {
       ffa_u32x4 v = *reinterpret_cast<const ffa_u32x4*>(ep + t * GEP + fp * 16);
-      if (g.residual) {
-        float o[8], r[8];
+      if (g.residual || g.aux || g.row_scale) {  // block-uniform
+        float o[8];
         ffa_load8<ffa_bf16>(reinterpret_cast<const ffa_bf16*>(&v), o);
-        ffa_load8<ffa_bf16>(g.residual + (long long)row * g.ldr + col, r);
+        if (g.aux) {
+          if (g.act == FFA_ACT_GELU) {  // keep the (bf16-rounded) pre-activation for the backward pass
+            *reinterpret_cast<ffa_u32x4*>(g.aux + (long long)row * g.ldaux + col) = v;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += r[e];
+            for (int e = 0; e < 8; ++e) o[e] = gemm_gelu(o[e]);
+          } else if (g.act == FFA_ACT_DGELU) {
+            float u[8];
+            ffa_load8<ffa_bf16>(g.aux + (long long)row * g.ldaux + col, u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] *= gemm_dgelu(u[e]);
+          }
+        }
+        if (g.row_scale) {
+          const float sc = g.row_scale[row / g.rows_per_scale];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] *= sc;
+        }
+        if (g.residual) {
+          float r[8];
+          ffa_load8<ffa_bf16>(g.residual + (long long)row * g.ldr + col, r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += r[e];
+        }
         ffa_store8<ffa_bf16>(g.out + (long long)row * g.ldc + col, o);
       } else {
         *reinterpret_cast<ffa_u32x4*>(g.out + (long long)row * g.ldc + col) = v;
@@ -183,25 +215,38 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs g) {
   }
 }
 
-extern "C" int ffa_linear(int dtype, const void* a, long long lda, const void* w, const float* bias, const void* residual,
-                          long long ldr, void* out, long long ldc, int M, int K, int N, int act, hipStream_t stream) {
+extern "C" int ffa_linear_ex(int dtype, const void* a, long long lda, const void* w, const float* bias,
+                             const void* residual, long long ldr, void* out, long long ldc, int M, int K, int N, int act,
+                             void* aux, long long ldaux, const float* row_scale, int rows_per_scale,
+                             hipStream_t stream) {
   FFA_REQUIRE(dtype == FFA_BF16, "linear: only the bf16 token GEMM is built (the f32 parity mode uses ffa_conv2d 1x1)");
   FFA_REQUIRE(a && w && out && M > 0 && K > 0 && N > 0, "linear: bad arguments");
   FFA_REQUIRE(K % 32 == 0 && N % 8 == 0, "linear: K = %d must be a multiple of 32 and N = %d of 8", K, N);
-  FFA_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 8 == 0 && (!residual || (ldr >= N && ldr % 8 == 0)),
+  FFA_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 8 == 0 && (!residual || (ldr >= N && ldr % 8 == 0)) &&
+                  (!aux || (ldaux >= N && ldaux % 8 == 0)),
               "linear: row pitches must cover the row and be multiples of 8 elements");
-  FFA_REQUIRE(act == FFA_ACT_NONE || act == FFA_ACT_GELU, "linear: unknown activation %d", act);
+  FFA_REQUIRE(act == FFA_ACT_NONE || act == FFA_ACT_GELU || (act == FFA_ACT_DGELU && aux), "linear: activation %d", act);
+  FFA_REQUIRE(!(aux && act == FFA_ACT_NONE), "linear: an auxiliary tensor needs the GELU / DGELU epilogue");
+  FFA_REQUIRE(!row_scale || rows_per_scale > 0, "linear: rows_per_scale must be positive");
   GemmArgs g;
   g.a = (const ffa_bf16*)a;
   g.w = (const ffa_bf16*)w;
   g.bias = bias;
   g.residual = (const ffa_bf16*)residual;
   g.out = (ffa_bf16*)out;
-  g.lda = lda; g.ldr = ldr; g.ldc = ldc;
+  g.aux = (ffa_bf16*)aux;
+  g.row_scale = row_scale;
+  g.lda = lda; g.ldr = ldr; g.ldc = ldc; g.ldaux = ldaux;
   g.M = M; g.K = K; g.N = N; g.act = act;
+  g.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
   g.nblk_n = (N + GBN - 1) / GBN;
   const long long blocks = (long long)((M + GBM - 1) / GBM) * g.nblk_n;
   FFA_REQUIRE(blocks < (1LL << 31), "linear: grid too large");
   hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g);
   return ffa_check_launch("linear");
+}
+
+extern "C" int ffa_linear(int dtype, const void* a, long long lda, const void* w, const float* bias, const void* residual,
+                          long long ldr, void* out, long long ldc, int M, int K, int N, int act, hipStream_t stream) {
+  return ffa_linear_ex(dtype, a, lda, w, bias, residual, ldr, out, ldc, M, K, N, act, nullptr, 0, nullptr, 0, stream);
 }

@@ -78,8 +78,8 @@ extern "C" int ffa_space_to_depth(int dtype, const void* in, void* out, int B, i
 template <typename T, bool MERGE, int LPR, int GPL>
 __global__ void __launch_bounds__(256) layer_norm_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                          const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, long long rows, int C, int Ho,
-                                                         int Wo, float eps) {
+                                                         const float* __restrict__ beta, float* __restrict__ stats,
+                                                         long long rows, int C, int Ho, int Wo, float eps) {
   constexpr int RPB = 256 / LPR;  // rows per block
   const int sub = threadIdx.x % LPR;
   const long long row = blockIdx.x * (long long)RPB + threadIdx.x / LPR;
@@ -134,6 +134,10 @@ __global__ void __launch_bounds__(256) layer_norm_kernel(const T* __restrict__ x
   for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
   const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
   if (!live) return;
+  if (stats && sub == 0) {  // kept for the backward pass (training)
+    stats[row * 2] = mean;
+    stats[row * 2 + 1] = rstd;
+  }
 #pragma unroll
   for (int j = 0; j < GPL; ++j) {
     const int g = sub + LPR * j;
@@ -149,12 +153,12 @@ __global__ void __launch_bounds__(256) layer_norm_kernel(const T* __restrict__ x
 }
 
 template <typename T, bool MERGE>
-static int layer_norm_launch(const void* x, void* y, const float* gamma, const float* beta, long long rows, int C, int Ho,
-                             int Wo, float eps, hipStream_t stream) {
+static int layer_norm_launch(const void* x, void* y, const float* gamma, const float* beta, float* stats, long long rows,
+                             int C, int Ho, int Wo, float eps, hipStream_t stream) {
   const int CG = C / 8;
 #define FFA_LN_CASE(LPR, GPL)                                                                                        \
   hipLaunchKernelGGL((layer_norm_kernel<T, MERGE, LPR, GPL>), dim3((unsigned)((rows + 256 / LPR - 1) / (256 / LPR))), \
-                     dim3(256), 0, stream, (const T*)x, (T*)y, gamma, beta, rows, C, Ho, Wo, eps)
+                     dim3(256), 0, stream, (const T*)x, (T*)y, gamma, beta, stats, rows, C, Ho, Wo, eps)
   if (CG <= 16) FFA_LN_CASE(16, 1);
   else if (CG <= 32) FFA_LN_CASE(32, 1);
   else if (CG <= 64) FFA_LN_CASE(64, 1);
@@ -169,21 +173,243 @@ static int layer_norm_launch(const void* x, void* y, const float* gamma, const f
   return ffa_check_launch(MERGE ? "patch_merge_norm" : "layer_norm");
 }
 
-extern "C" int ffa_layer_norm(int dtype, const void* x, void* y, const float* gamma, const float* beta, long long rows,
-                              int C, float eps, hipStream_t stream) {
+extern "C" int ffa_layer_norm(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* stats,
+                              long long rows, int C, float eps, hipStream_t stream) {
   FFA_REQUIRE(x && y && gamma && beta && rows > 0 && C > 0 && C % 8 == 0, "layer_norm: bad arguments");
-  if (dtype == FFA_BF16) return layer_norm_launch<ffa_bf16, false>(x, y, gamma, beta, rows, C, 0, 0, eps, stream);
-  return layer_norm_launch<float, false>(x, y, gamma, beta, rows, C, 0, 0, eps, stream);
+  if (dtype == FFA_BF16) return layer_norm_launch<ffa_bf16, false>(x, y, gamma, beta, stats, rows, C, 0, 0, eps, stream);
+  return layer_norm_launch<float, false>(x, y, gamma, beta, stats, rows, C, 0, 0, eps, stream);
 }
 
-extern "C" int ffa_patch_merge_norm(int dtype, const void* x, void* y, const float* gamma, const float* beta, int B,
-                                    int H, int W, int C, float eps, hipStream_t stream) {
+extern "C" int ffa_patch_merge_norm(int dtype, const void* x, void* y, const float* gamma, const float* beta,
+                                    float* stats, int B, int H, int W, int C, float eps, hipStream_t stream) {
   FFA_REQUIRE(x && y && gamma && beta && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "patch_merge_norm: bad arguments");
   FFA_REQUIRE(H % 2 == 0 && W % 2 == 0, "patch_merge_norm: odd map %d x %d (the padded variant is not implemented)", H, W);
   const long long rows = (long long)B * (H / 2) * (W / 2);
   if (dtype == FFA_BF16)
-    return layer_norm_launch<ffa_bf16, true>(x, y, gamma, beta, rows, 4 * C, H / 2, W / 2, eps, stream);
-  return layer_norm_launch<float, true>(x, y, gamma, beta, rows, 4 * C, H / 2, W / 2, eps, stream);
+    return layer_norm_launch<ffa_bf16, true>(x, y, gamma, beta, stats, rows, 4 * C, H / 2, W / 2, eps, stream);
+  return layer_norm_launch<float, true>(x, y, gamma, beta, stats, rows, 4 * C, H / 2, W / 2, eps, stream);
+}
+
+// ---- LayerNorm backward.  dx: the forward's lane layout (one read of x and dy, one write), row statistics taken from
+// the forward pass:  xhat = (x - mean) rstd, g = dy gamma, dx = rstd (g - mean_c(g) - xhat mean_c(g xhat)).
+// MERGE: x is read through PatchMerging's gather and dx scattered back through it (every input element belongs to
+// exactly one merged row).  dgamma / dbeta: a second pass over row chunks (per-thread 8 channels x a strided set of
+// rows, block partials to the workspace) and a fixed-order sum of the chunk partials -- deterministic.
+
+template <typename T, bool MERGE, int LPR, int GPL>
+__global__ void __launch_bounds__(256) layer_norm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ stats,
+                                                             const T* __restrict__ dres, T* __restrict__ dx,
+                                                             long long rows, int C, int Ho, int Wo) {
+  constexpr int RPB = 256 / LPR;
+  const int sub = threadIdx.x % LPR;
+  const long long row = blockIdx.x * (long long)RPB + threadIdx.x / LPR;
+  const bool live = row < rows;
+  const int CG = C / 8;
+  const int Cs = MERGE ? C / 4 : C;
+  const int CGs = Cs / 8;
+  long long base[4] = {0, 0, 0, 0};
+  float mean = 0.f, rstd = 0.f;
+  if (live) {
+    if (MERGE) {
+      const int xo = (int)(row % Wo);
+      const long long t = row / Wo;
+      const int yo = (int)(t % Ho);
+      const long long b = t / Ho;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        base[s] = ((b * (2 * Ho) + 2 * yo + (s & 1)) * (2LL * Wo) + 2 * xo + (s >> 1)) * Cs;
+    } else {
+      base[0] = row * (long long)C;
+    }
+    mean = stats[row * 2];
+    rstd = stats[row * 2 + 1];
+  }
+  float xh[GPL][8], gg[GPL][8];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < GPL; ++j) {
+    const int g = sub + LPR * j;
+    if (live && g < CG) {
+      const long long off = MERGE ? base[g / CGs] + (g % CGs) * 8 : base[0] + g * 8;
+      float xv[8], dv[8], ga[8];
+      ffa_load8<T>(x + off, xv);
+      ffa_load8<T>(dy + row * (long long)C + g * 8, dv);
+      ffa_load8<float>(gamma + g * 8, ga);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xh[j][e] = (xv[e] - mean) * rstd;
+        gg[j][e] = dv[e] * ga[e];
+        s1 += gg[j][e];
+        s2 += gg[j][e] * xh[j][e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xh[j][e] = gg[j][e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if (!live) return;
+  const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+#pragma unroll
+  for (int j = 0; j < GPL; ++j) {
+    const int g = sub + LPR * j;
+    if (g < CG) {
+      const long long off = MERGE ? base[g / CGs] + (g % CGs) * 8 : base[0] + g * 8;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = rstd * (gg[j][e] - m1 - xh[j][e] * m2);
+      if (dres) {  // the residual connection around the normalised branch: dx = dres + LayerNorm'(dy)
+        float r[8];
+        ffa_load8<T>(dres + off, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += r[e];
+      }
+      ffa_store8<T>(dx + off, o);
+    }
+  }
+}
+
+// partial[chunk][0][c] = sum_r dy xhat, partial[chunk][1][c] = sum_r dy over the chunk's rows
+template <typename T, bool MERGE>
+__global__ void __launch_bounds__(256) layer_norm_bwd_params_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                    const float* __restrict__ stats,
+                                                                    float* __restrict__ partial, long long rows, int C,
+                                                                    int Ho, int Wo, long long rows_per_chunk) {
+  __shared__ float red[8][32][16];
+  const int CG = C / 8;
+  const int Cs = MERGE ? C / 4 : C;
+  const int CGs = Cs / 8;
+  const int gl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int g = blockIdx.x * 32 + gl;
+  const long long r0 = blockIdx.y * rows_per_chunk;
+  long long r1 = r0 + rows_per_chunk;
+  if (r1 > rows) r1 = rows;
+  float acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  if (g < CG) {
+    for (long long row = r0 + rl; row < r1; row += 8) {
+      long long off;
+      if (MERGE) {
+        const int xo = (int)(row % Wo);
+        const long long t = row / Wo;
+        const int yo = (int)(t % Ho);
+        const long long b = t / Ho;
+        const int s = g / CGs;
+        off = ((b * (2 * Ho) + 2 * yo + (s & 1)) * (2LL * Wo) + 2 * xo + (s >> 1)) * Cs + (g % CGs) * 8;
+      } else {
+        off = row * (long long)C + g * 8;
+      }
+      float xv[8], dv[8];
+      ffa_load8<T>(x + off, xv);
+      ffa_load8<T>(dy + row * (long long)C + g * 8, dv);
+      const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        acc[e] += dv[e] * ((xv[e] - mean) * rstd);
+        acc[8 + e] += dv[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[rl][gl][e] = acc[e];
+  __syncthreads();
+  if (rl == 0 && g < CG) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v += red[r][gl][e];
+      partial[((long long)blockIdx.y * 2 + (e >> 3)) * C + g * 8 + (e & 7)] = v;
+    }
+  }
+}
+
+__global__ void layer_norm_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                             float* __restrict__ dbeta, int C, int chunks) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < chunks; ++k) {
+    a += partial[((long long)k * 2) * C + c];
+    b += partial[((long long)k * 2 + 1) * C + c];
+  }
+  dgamma[c] = a;
+  dbeta[c] = b;
+}
+
+static inline int ln_bwd_chunks(long long rows) {
+  long long c = (rows + 255) / 256;
+  if (c > 512) c = 512;
+  if (c < 1) c = 1;
+  return (int)c;
+}
+
+extern "C" long long ffa_layer_norm_bwd_workspace_bytes(long long rows, int C) {
+  return (long long)ln_bwd_chunks(rows) * 2 * C * (long long)sizeof(float);
+}
+
+template <typename T, bool MERGE>
+static int layer_norm_bwd_launch(const void* x, const void* dy, const float* gamma, const float* stats,
+                                 const void* dres, void* dx, float* dgamma, float* dbeta, long long rows, int C, int Ho, int Wo, void* workspace,
+                                 long long workspace_bytes, hipStream_t stream) {
+  const int CG = C / 8;
+  if (workspace_bytes < ffa_layer_norm_bwd_workspace_bytes(rows, C) || !workspace) {
+    ffa_set_error("layer_norm_bwd: workspace of %lld bytes needed", ffa_layer_norm_bwd_workspace_bytes(rows, C));
+    return FFA_ERR_WORKSPACE;
+  }
+#define FFA_LNB_CASE(LPR, GPL)                                                                                            \
+  hipLaunchKernelGGL((layer_norm_bwd_kernel<T, MERGE, LPR, GPL>), dim3((unsigned)((rows + 256 / LPR - 1) / (256 / LPR))), \
+                     dim3(256), 0, stream, (const T*)x, (const T*)dy, gamma, stats, (const T*)dres, (T*)dx, rows, C, Ho, Wo)
+  if (CG <= 16) FFA_LNB_CASE(16, 1);
+  else if (CG <= 32) FFA_LNB_CASE(32, 1);
+  else if (CG <= 64) FFA_LNB_CASE(64, 1);
+  else if (CG <= 128) FFA_LNB_CASE(64, 2);
+  else if (CG <= 256) FFA_LNB_CASE(64, 4);
+  else if (CG <= 512) FFA_LNB_CASE(64, 8);
+  else {
+    ffa_set_error("layer_norm_bwd: C = %d exceeds 4096", C);
+    return FFA_ERR_UNSUPPORTED;
+  }
+#undef FFA_LNB_CASE
+  const int chunks = ln_bwd_chunks(rows);
+  const long long rpc = (rows + chunks - 1) / chunks;
+  hipLaunchKernelGGL((layer_norm_bwd_params_kernel<T, MERGE>), dim3((unsigned)((CG + 31) / 32), (unsigned)chunks), dim3(256),
+                     0, stream, (const T*)x, (const T*)dy, stats, (float*)workspace, rows, C, Ho, Wo, rpc);
+  hipLaunchKernelGGL(layer_norm_bwd_reduce_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream,
+                     (const float*)workspace, dgamma, dbeta, C, chunks);
+  return ffa_check_launch(MERGE ? "patch_merge_norm_bwd" : "layer_norm_bwd");
+}
+
+extern "C" int ffa_layer_norm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* stats,
+                                  const void* dres, void* dx, float* dgamma, float* dbeta, long long rows, int C, void* workspace,
+                                  long long workspace_bytes, hipStream_t stream) {
+  FFA_REQUIRE(x && dy && gamma && stats && dx && dgamma && dbeta && rows > 0 && C > 0 && C % 8 == 0,
+              "layer_norm_bwd: bad arguments");
+  if (dtype == FFA_BF16)
+    return layer_norm_bwd_launch<ffa_bf16, false>(x, dy, gamma, stats, dres, dx, dgamma, dbeta, rows, C, 0, 0, workspace,
+                                                  workspace_bytes, stream);
+  return layer_norm_bwd_launch<float, false>(x, dy, gamma, stats, dres, dx, dgamma, dbeta, rows, C, 0, 0, workspace,
+                                             workspace_bytes, stream);
+}
+
+extern "C" int ffa_patch_merge_norm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* stats,
+                                        void* dx, float* dgamma, float* dbeta, int B, int H, int W, int C, void* workspace,
+                                        long long workspace_bytes, hipStream_t stream) {
+  FFA_REQUIRE(x && dy && gamma && stats && dx && dgamma && dbeta && B > 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0 &&
+                  H % 2 == 0 && W % 2 == 0, "patch_merge_norm_bwd: bad arguments");
+  const long long rows = (long long)B * (H / 2) * (W / 2);
+  if (dtype == FFA_BF16)
+    return layer_norm_bwd_launch<ffa_bf16, true>(x, dy, gamma, stats, nullptr, dx, dgamma, dbeta, rows, 4 * C, H / 2, W / 2,
+                                                 workspace, workspace_bytes, stream);
+  return layer_norm_bwd_launch<float, true>(x, dy, gamma, stats, nullptr, dx, dgamma, dbeta, rows, 4 * C, H / 2, W / 2,
+                                            workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -680,4 +906,547 @@ extern "C" int ffa_bilinear_slice(int dtype, const void* x, const void* addend, 
                        (const float*)x, (const float*)addend, (float*)y, B, Hi, Wi, Ho, Wo, C, y_pitch, y_off,
                        align_corners ? 1 : 0, sy, sx);
   return ffa_check_launch("bilinear_slice");
+}
+
+// ---- backward of ffa_bilinear_slice in GATHER form (the scheme of bilinear_bwd_kernel in resample_loss.hip, with
+// either corner convention and the gradient read from a channel slice of a wider tensor): one thread per 8 channels of
+// a SOURCE pixel walks the destination pixels whose footprint contains it; membership and weights come from the very
+// bilinear_src2() the forward uses; fixed summation order, no atomics.
+template <typename T>
+__global__ void bilinear_slice_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int Hi, int Wi, int Ho,
+                                          int Wo, int C, int y_pitch, int y_off, int align, float sy, float sx) {
+  const int CG = C / 8;
+  const long long total = (long long)B * Hi * Wi * CG;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % CG);
+    long long p = i / CG;
+    const int x = (int)(p % Wi);
+    p /= Wi;
+    const int y = (int)(p % Hi);
+    const long long b = p / Hi;
+    // candidate destination rows / columns: source coordinate within one pixel of (y, x), one extra on each side for
+    // the float rounding of the bounds; exact membership is decided per candidate below
+    int oy_lo = 0, oy_hi = Ho - 1, ox_lo = 0, ox_hi = Wo - 1;
+    if (sy > 1e-12f) {
+      const float a = align ? ((float)y - 1.0f) / sy : ((float)y - 0.5f) / sy - 0.5f;
+      const float c = align ? ((float)y + 1.0f) / sy : ((float)y + 1.5f) / sy - 0.5f;
+      oy_lo = (int)floorf(a) - 1;
+      oy_hi = (int)ceilf(c) + 1;
+    }
+    if (sx > 1e-12f) {
+      const float a = align ? ((float)x - 1.0f) / sx : ((float)x - 0.5f) / sx - 0.5f;
+      const float c = align ? ((float)x + 1.0f) / sx : ((float)x + 1.5f) / sx - 0.5f;
+      ox_lo = (int)floorf(a) - 1;
+      ox_hi = (int)ceilf(c) + 1;
+    }
+    oy_lo = oy_lo < 0 ? 0 : oy_lo;
+    ox_lo = ox_lo < 0 ? 0 : ox_lo;
+    oy_hi = oy_hi > Ho - 1 ? Ho - 1 : oy_hi;
+    ox_hi = ox_hi > Wo - 1 ? Wo - 1 : ox_hi;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1;
+      float ly0, ly1;
+      bilinear_src2(oy, sy, Hi, align, y0, y1, ly0, ly1);
+      if (y0 != y && y1 != y) continue;
+      const float wy = (y0 == y ? ly0 : 0.f) + (y1 == y ? ly1 : 0.f);  // y0 == y1 on the clamped last row
+      float row[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) row[e] = 0.f;
+      const T* drow = dy + ((b * Ho + oy) * Wo) * y_pitch + y_off + g * 8;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1;
+        float lx0, lx1;
+        bilinear_src2(ox, sx, Wi, align, x0, x1, lx0, lx1);
+        if (x0 != x && x1 != x) continue;
+        const float wx = (x0 == x ? lx0 : 0.f) + (x1 == x ? lx1 : 0.f);
+        float gv[8];
+        ffa_load8<T>(drow + (long long)ox * y_pitch, gv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) row[e] += wx * gv[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += wy * row[e];
+    }
+    ffa_store8<T>(dx + i * 8, acc);
+  }
+}
+
+extern "C" int ffa_bilinear_slice_bwd(int dtype, const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                      int y_pitch, int y_off, int align_corners, hipStream_t stream) {
+  FFA_REQUIRE(dy && dx && C > 0 && C % 8 == 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && B > 0,
+              "bilinear_slice_bwd: bad arguments");
+  FFA_REQUIRE(y_pitch % 8 == 0 && y_off % 8 == 0 && y_off >= 0 && y_off + C <= y_pitch,
+              "bilinear_slice_bwd: slice [%d, %d) does not fit pitch %d", y_off, y_off + C, y_pitch);
+  float sy, sx;
+  if (align_corners) {
+    sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+    sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  } else {
+    sy = (float)Hi / (float)Ho;
+    sx = (float)Wi / (float)Wo;
+  }
+  const long long items = (long long)B * Hi * Wi * (C / 8);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(bilinear_slice_bwd_kernel<ffa_bf16>, dim3(tf_grid(items)), dim3(FFA_TF_THREADS), 0, stream,
+                       (const ffa_bf16*)dy, (ffa_bf16*)dx, B, Hi, Wi, Ho, Wo, C, y_pitch, y_off, align_corners ? 1 : 0,
+                       sy, sx);
+  else
+    hipLaunchKernelGGL(bilinear_slice_bwd_kernel<float>, dim3(tf_grid(items)), dim3(FFA_TF_THREADS), 0, stream,
+                       (const float*)dy, (float*)dx, B, Hi, Wi, Ho, Wo, C, y_pitch, y_off, align_corners ? 1 : 0, sy,
+                       sx);
+  return ffa_check_launch("bilinear_slice_bwd");
+}
+
+// ---- backward of nn.AdaptiveAvgPool2d(S): dx[b][y][x] = sum over the output cells whose region holds (y, x) of
+// dy[b][oy][ox] / area(oy, ox) (regions overlap when S does not divide the map)
+template <typename T>
+__global__ void adaptive_avg_pool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int C,
+                                             int S) {
+  const int CG = C / 8;
+  const long long total = (long long)B * H * W * CG;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % CG);
+    long long p = i / CG;
+    const int x = (int)(p % W);
+    p /= W;
+    const int y = (int)(p % H);
+    const long long b = p / H;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int oy = 0; oy < S; ++oy) {
+      const int y0 = (oy * H) / S, y1 = ((oy + 1) * H + S - 1) / S;
+      if (y < y0 || y >= y1) continue;
+      for (int ox = 0; ox < S; ++ox) {
+        const int x0 = (ox * W) / S, x1 = ((ox + 1) * W + S - 1) / S;
+        if (x < x0 || x >= x1) continue;
+        const float inv = 1.0f / (float)((y1 - y0) * (x1 - x0));
+        float gv[8];
+        ffa_load8<T>(dy + ((b * S + oy) * S + ox) * C + g * 8, gv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += gv[e] * inv;
+      }
+    }
+    ffa_store8<T>(dx + i * 8, acc);
+  }
+}
+
+extern "C" int ffa_adaptive_avg_pool_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int C, int S,
+                                         hipStream_t stream) {
+  FFA_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && S > 0, "adaptive_avg_pool_bwd: bad arguments");
+  const long long items = (long long)B * H * W * (C / 8);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(adaptive_avg_pool_bwd_kernel<ffa_bf16>, dim3(tf_grid(items)), dim3(FFA_TF_THREADS), 0, stream,
+                       (const ffa_bf16*)dy, (ffa_bf16*)dx, B, H, W, C, S);
+  else
+    hipLaunchKernelGGL(adaptive_avg_pool_bwd_kernel<float>, dim3(tf_grid(items)), dim3(FFA_TF_THREADS), 0, stream,
+                       (const float*)dy, (float*)dx, B, H, W, C, S);
+  return ffa_check_launch("adaptive_avg_pool_bwd");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Window attention backward (bf16, MFMA 16x16x32).  One block per (window, head); q, k, v and dO of the window's
+// tokens are staged once in LDS (row-major [NP][32] at a 96-byte pitch: row fragments by ds_read_b128, transposed
+// fragments by ds_read_b64_tr_b16).  Two passes over the recomputed probabilities, as in flash-attention's backward:
+//   pass A, lanes = queries:  S^T = K Q^T, row max / sum, dP^T = V dO^T, delta = sum_k P dP, dS = P (dP - delta),
+//           d table[idx(q, k)] += dS (LDS atomics, flushed once per block), dQ^T = scale K^T dS^T;
+//           row max, 1 / sum and delta go to LDS for pass B
+//   pass B, lanes = keys:     S = Q K^T again in the other orientation, P, dP = dO V^T, dS,
+//           dV^T += dO^T P, dK^T += scale Q^T dS   (the query index is the MFMA's k dimension, taken from registers)
+// Every real token belongs to exactly one window, so dqkv is written without atomics; the gradients of padding tokens
+// (whose q / k / v are the qkv bias) go to dbias_pad[3C] with atomics, like the bias-table gradient (nn.Parameter
+// indexing has an atomic backward in torch as well).
+template <int NTP, int NW>
+__global__ void __launch_bounds__(64 * NW) window_attention_bwd_kernel(WinAttnArgs a, const ffa_bf16* __restrict__ dout,
+                                                                       ffa_bf16* __restrict__ dqkv,
+                                                                       float* __restrict__ dtable,
+                                                                       float* __restrict__ dbias_pad) {
+  constexpr int NP = NTP * 16;
+  constexpr int RP = 96;  // row pitch in bytes
+  constexpr float LOG2E = 1.4426950408889634f;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * NP * RP + NP * 16 + 2 * 529 * 4];
+  unsigned char* sq = smem;
+  unsigned char* sk = sq + NP * RP;
+  unsigned char* sv = sk + NP * RP;
+  unsigned char* sdo = sv + NP * RP;
+  int* skey = reinterpret_cast<int*>(sdo + NP * RP);          // [NP] lin | rid << 16
+  float* sm = reinterpret_cast<float*>(skey + NP);            // [NP] row max (log2 units)
+  float* sli = sm + NP;                                       // [NP] 1 / row sum
+  float* sdelta = sli + NP;                                   // [NP]
+  float* stab = sdelta + NP;                                  // [529]
+  float* sdtab = stab + 529;                                  // [529]
+  const int N = a.ws * a.ws;
+  const int head = blockIdx.y;
+  int w = blockIdx.x;
+  const int wx = w % a.nwx;
+  w /= a.nwx;
+  const int wy = w % a.nwy;
+  const int b = w / a.nwy;
+  const ffa_bf16* qkv = (const ffa_bf16*)a.qkv;
+  const int C3 = 3 * a.C;
+  const int TS = (2 * a.ws - 1) * (2 * a.ws - 1);
+  for (int i = threadIdx.x; i < TS; i += 64 * NW) {
+    stab[i] = a.table[i * a.heads + head] * LOG2E;
+    sdtab[i] = 0.f;
+  }
+  const float scale2 = a.scale * LOG2E;
+  const bool masked = a.shift > 0 && (wy == a.nwy - 1 || wx == a.nwx - 1);
+  for (int i = threadIdx.x; i < NP * 4; i += 64 * NW) {
+    const int t = i >> 2, pc = i & 3;
+    const int c = head * 32 + pc * 8;
+    ffa_u32x4 q4 = {0u, 0u, 0u, 0u}, k4 = q4, v4 = q4, d4 = q4;
+    int packed = 0xffff0000;
+    if (t < N) {
+      const WinTok tk = win_token(a, b, wy, wx, t);
+      packed = tk.lin | (tk.rid << 16);
+      if (tk.off >= 0) {
+        const ffa_bf16* p = qkv + tk.off * C3 + c;
+        q4 = *reinterpret_cast<const ffa_u32x4*>(p);
+        k4 = *reinterpret_cast<const ffa_u32x4*>(p + a.C);
+        v4 = *reinterpret_cast<const ffa_u32x4*>(p + 2 * a.C);
+        d4 = *reinterpret_cast<const ffa_u32x4*>(dout + tk.off * a.C + c);
+      } else {
+        float qf[8], kf[8], vf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          qf[e] = a.qkv_bias[c + e];
+          kf[e] = a.qkv_bias[a.C + c + e];
+          vf[e] = a.qkv_bias[2 * a.C + c + e];
+        }
+        ffa_store8<ffa_bf16>(reinterpret_cast<ffa_bf16*>(&q4), qf);
+        ffa_store8<ffa_bf16>(reinterpret_cast<ffa_bf16*>(&k4), kf);
+        ffa_store8<ffa_bf16>(reinterpret_cast<ffa_bf16*>(&v4), vf);
+      }
+    }
+    *reinterpret_cast<ffa_u32x4*>(sq + t * RP + pc * 16) = q4;
+    *reinterpret_cast<ffa_u32x4*>(sk + t * RP + pc * 16) = k4;
+    *reinterpret_cast<ffa_u32x4*>(sv + t * RP + pc * 16) = v4;
+    *reinterpret_cast<ffa_u32x4*>(sdo + t * RP + pc * 16) = d4;
+    if (pc == 0) skey[t] = packed;
+  }
+  __syncthreads();
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = lane & 15, g = lane >> 4;
+  const int off0 = (a.ws - 1) * (2 * a.ws - 1) + (a.ws - 1);
+  const int nqt = (N + 15) / 16;
+  const int tr_off = ((lane >> 2) & 3) * RP + (lane & 3) * 8;
+  auto tr_frag = [&](const unsigned char* img, int u, int dhalf) -> ffa_bf16x8 {
+    // transposed 16 x 32 fragment: rows (tokens) 32u + 4g .. +3 and 32u + 16 + 4g .. +3, channels 16 dhalf + lane % 16
+    const unsigned char* p = img + (u * 32 + g * 4) * RP + tr_off + dhalf * 32;
+    const ffa_s16x4 lo = attn_read_tr16(p);
+    const ffa_s16x4 hi = attn_read_tr16(p + 16 * RP);
+    ffa_u32x4 v;
+    v.x = __builtin_bit_cast(ffa_u32x2, lo).x; v.y = __builtin_bit_cast(ffa_u32x2, lo).y;
+    v.z = __builtin_bit_cast(ffa_u32x2, hi).x; v.w = __builtin_bit_cast(ffa_u32x2, hi).y;
+    return __builtin_bit_cast(ffa_bf16x8, v);
+  };
+  // token -> (element offset or -1) for the output stores of this lane's token (tile * 16 + n)
+  auto token_off = [&](int t) -> long long { return t < N ? win_token(a, b, wy, wx, t).off : -2; };
+  auto store_grad = [&](int t, int which, const ffa_f32x4& lo, const ffa_f32x4& hi, float mul) {
+    const long long off = token_off(t);
+    if (off >= 0) {
+      ffa_bf16* dst = dqkv + off * C3 + which * a.C + head * 32 + g * 4;
+      uint2 l2, h2;
+      l2.x = ffa_pack_bf16x2(lo[0] * mul, lo[1] * mul);
+      l2.y = ffa_pack_bf16x2(lo[2] * mul, lo[3] * mul);
+      h2.x = ffa_pack_bf16x2(hi[0] * mul, hi[1] * mul);
+      h2.y = ffa_pack_bf16x2(hi[2] * mul, hi[3] * mul);
+      *reinterpret_cast<uint2*>(dst) = l2;
+      *reinterpret_cast<uint2*>(dst + 16) = h2;
+    } else if (off == -1) {  // padding token inside the window: its q / k / v are the bias
+      float* dst = dbias_pad + which * a.C + head * 32 + g * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        atomicAdd(dst + e, lo[e] * mul);
+        atomicAdd(dst + 16 + e, hi[e] * mul);
+      }
+    }
+  };
+
+  // ---------------- pass A: lanes = queries
+  for (int qt = wave; qt < nqt; qt += NW) {
+    const int qi = qt * 16 + n;
+    const ffa_bf16x8 qf = *reinterpret_cast<const ffa_bf16x8*>(sq + qi * RP + g * 16);
+    const ffa_bf16x8 dof = *reinterpret_cast<const ffa_bf16x8*>(sdo + qi * RP + g * 16);
+    const int qk = skey[qi];
+    const int qlin = off0 + (qk & 0xffff), qrid = qk >> 16;
+    ffa_f32x4 s[NTP], dp[NTP];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NTP; ++t) {
+      if (t >= nqt) {
+        s[t] = ffa_f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        dp[t] = ffa_f32x4{0.f, 0.f, 0.f, 0.f};
+        continue;
+      }
+      const ffa_bf16x8 kf = *reinterpret_cast<const ffa_bf16x8*>(sk + (t * 16 + n) * RP + g * 16);
+      const ffa_bf16x8 vf = *reinterpret_cast<const ffa_bf16x8*>(sv + (t * 16 + n) * RP + g * 16);
+      const int4 key4 = *reinterpret_cast<const int4*>(&skey[t * 16 + g * 4]);
+      ffa_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acd = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, acc, 0, 0, 0);
+      acd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof, acd, 0, 0, 0);
+      const int kk[4] = {key4.x, key4.y, key4.z, key4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = acc[i] * scale2 + stab[qlin - (kk[i] & 0xffff)];
+        if (masked && (kk[i] >> 16) != qrid) v += -100.0f * LOG2E;
+        if (kk[i] < 0) v = -INFINITY;
+        acc[i] = v;
+        mx = fmaxf(mx, v);
+      }
+      s[t] = acc;
+      dp[t] = acd;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTP; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float e = __builtin_amdgcn_exp2f(s[t][i] - mx);
+        s[t][i] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    float delta = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTP; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s[t][i] *= inv;
+        delta += s[t][i] * dp[t][i];
+      }
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+    if (g == 0) {
+      sm[qi] = mx;
+      sli[qi] = inv;
+      sdelta[qi] = delta;
+    }
+#pragma unroll
+    for (int t = 0; t < NTP; ++t) {
+      if (t >= nqt) continue;
+      const int4 key4 = *reinterpret_cast<const int4*>(&skey[t * 16 + g * 4]);
+      const int kk[4] = {key4.x, key4.y, key4.z, key4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float ds = s[t][i] * (dp[t][i] - delta);
+        s[t][i] = ds;
+        if (ds != 0.f) atomicAdd(&sdtab[qlin - (kk[i] & 0xffff)], ds);
+      }
+    }
+    ffa_f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NTP / 2; ++u) {
+      ffa_bf16x8 df;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        df[i] = (__bf16)s[2 * u][i];
+        df[4 + i] = (__bf16)s[2 * u + 1][i];
+      }
+      q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sk, u, 0), df, q0, 0, 0, 0);
+      q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sk, u, 1), df, q1, 0, 0, 0);
+    }
+    store_grad(qi, 0, q0, q1, a.scale);
+  }
+  __syncthreads();
+
+  // ---------------- pass B: lanes = keys
+  for (int kt = wave; kt < nqt; kt += NW) {
+    const int ki = kt * 16 + n;
+    const ffa_bf16x8 kfb = *reinterpret_cast<const ffa_bf16x8*>(sk + ki * RP + g * 16);
+    const ffa_bf16x8 vfb = *reinterpret_cast<const ffa_bf16x8*>(sv + ki * RP + g * 16);
+    const int kk = skey[ki];
+    const int klin = kk & 0xffff, krid = kk >> 16;
+    ffa_f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, v0 = k0, v1 = k0;
+#pragma unroll
+    for (int u = 0; u < NTP / 2; ++u) {
+      ffa_bf16x8 pf, df;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int t = 2 * u + h;
+        ffa_f32x4 p = {0.f, 0.f, 0.f, 0.f}, ds = p;
+        if (t < nqt) {  // block-uniform
+          const ffa_bf16x8 qa = *reinterpret_cast<const ffa_bf16x8*>(sq + (t * 16 + n) * RP + g * 16);
+          const ffa_bf16x8 da = *reinterpret_cast<const ffa_bf16x8*>(sdo + (t * 16 + n) * RP + g * 16);
+          const int4 q4 = *reinterpret_cast<const int4*>(&skey[t * 16 + g * 4]);
+          const float4 m4 = *reinterpret_cast<const float4*>(&sm[t * 16 + g * 4]);
+          const float4 l4 = *reinterpret_cast<const float4*>(&sli[t * 16 + g * 4]);
+          const float4 d4 = *reinterpret_cast<const float4*>(&sdelta[t * 16 + g * 4]);
+          ffa_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acd = acc;
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kfb, acc, 0, 0, 0);   // rows: queries 4g + i, column: key n
+          acd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vfb, acd, 0, 0, 0);
+          const int qq[4] = {q4.x, q4.y, q4.z, q4.w};
+          const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
+          const float ll[4] = {l4.x, l4.y, l4.z, l4.w};
+          const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = acc[i] * scale2 + stab[off0 + (qq[i] & 0xffff) - klin];
+            if (masked && (qq[i] >> 16) != krid) v += -100.0f * LOG2E;
+            float pr = __builtin_amdgcn_exp2f(v - mm[i]) * ll[i];
+            if (krid < 0) pr = 0.f;
+            p[i] = pr;
+            ds[i] = pr * (acd[i] - dd[i]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          pf[4 * h + i] = (__bf16)p[i];
+          df[4 * h + i] = (__bf16)ds[i];
+        }
+      }
+      v0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sdo, u, 0), pf, v0, 0, 0, 0);
+      v1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sdo, u, 1), pf, v1, 0, 0, 0);
+      k0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sq, u, 0), df, k0, 0, 0, 0);
+      k1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sq, u, 1), df, k1, 0, 0, 0);
+    }
+    store_grad(ki, 1, k0, k1, a.scale);
+    store_grad(ki, 2, v0, v1, 1.0f);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TS; i += 64 * NW) {
+    const float v = sdtab[i];
+    if (v != 0.f) atomicAdd(&dtable[i * a.heads + head], v);
+  }
+}
+
+extern "C" int ffa_window_attention_bwd(int dtype, const void* qkv, const void* dout, void* dqkv, const float* qkv_bias,
+                                        const float* table, float* dtable, float* dbias_pad, int B, int H, int W, int C,
+                                        int heads, int ws, int shift, float scale, hipStream_t stream) {
+  FFA_REQUIRE(dtype == FFA_BF16, "window_attention_bwd: bf16 only (no f32 training mode for the transformer layers)");
+  FFA_REQUIRE(qkv && dout && dqkv && qkv_bias && table && dtable && dbias_pad && B > 0 && H > 0 && W > 0 && heads > 0,
+              "window_attention_bwd: bad arguments");
+  FFA_REQUIRE(C == heads * 32, "window_attention_bwd: head dimension %d (only 32 is built)", heads ? C / heads : 0);
+  FFA_REQUIRE(ws >= 1 && ws <= 12 && shift >= 0 && shift < ws, "window_attention_bwd: window %d / shift %d", ws, shift);
+  WinAttnArgs a;
+  a.qkv = qkv;
+  a.out = nullptr;
+  a.qkv_bias = qkv_bias;
+  a.table = table;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.heads = heads; a.ws = ws; a.shift = shift;
+  a.nwy = (H + ws - 1) / ws;
+  a.nwx = (W + ws - 1) / ws;
+  a.scale = scale;
+  const long long nwin = (long long)B * a.nwy * a.nwx;
+  FFA_REQUIRE(nwin < (1LL << 31) && heads < 65536, "window_attention_bwd: grid too large");
+  const dim3 grid((unsigned)nwin, (unsigned)heads);
+  if (ws * ws <= 64)
+    hipLaunchKernelGGL((window_attention_bwd_kernel<4, 4>), grid, dim3(256), 0, stream, a, (const ffa_bf16*)dout,
+                       (ffa_bf16*)dqkv, dtable, dbias_pad);
+  else
+    hipLaunchKernelGGL((window_attention_bwd_kernel<10, 3>), grid, dim3(192), 0, stream, a, (const ffa_bf16*)dout,
+                       (ffa_bf16*)dqkv, dtable, dbias_pad);
+  return ffa_check_launch("window_attention_bwd");
+}
+
+
+// ---- y[m][c] = x[m][c] * row_scale[m / rows_per_scale]: the DropPath factor on a gradient before the weight-gradient and
+// bias-gradient reductions (the GEMM epilogues apply it everywhere else)
+template <typename T>
+__global__ void scale_rows_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ row_scale,
+                                  long long rows, int C, int rows_per_scale) {
+  const int CG = C / 8;
+  const long long total = rows * CG;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float sc = row_scale[(i / CG) / rows_per_scale];
+    float v[8];
+    ffa_load8<T>(x + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= sc;
+    ffa_store8<T>(y + i * 8, v);
+  }
+}
+
+extern "C" int ffa_scale_rows(int dtype, const void* x, void* y, const float* row_scale, long long rows, int C,
+                              int rows_per_scale, hipStream_t stream) {
+  FFA_REQUIRE(x && y && row_scale && rows > 0 && C > 0 && C % 8 == 0 && rows_per_scale > 0, "scale_rows: bad arguments");
+  const long long items = rows * (C / 8);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(scale_rows_kernel<ffa_bf16>, dim3(tf_grid(items)), dim3(FFA_TF_THREADS), 0, stream,
+                       (const ffa_bf16*)x, (ffa_bf16*)y, row_scale, rows, C, rows_per_scale);
+  else
+    hipLaunchKernelGGL(scale_rows_kernel<float>, dim3(tf_grid(items)), dim3(FFA_TF_THREADS), 0, stream, (const float*)x,
+                       (float*)y, row_scale, rows, C, rows_per_scale);
+  return ffa_check_launch("scale_rows");
+}
+
+// ---- out[c] = sum_m x[m][c] (f32): nn.Linear's bias gradient for any width (ffa_channel_sums stops at 2048 channels).
+// Chunk partials in the workspace, summed in a fixed order: deterministic.
+template <typename T>
+__global__ void __launch_bounds__(256) column_sums_kernel(const T* __restrict__ x, float* __restrict__ partial,
+                                                          long long rows, int C, long long rows_per_chunk) {
+  __shared__ float red[8][32][8];
+  const int CG = C / 8;
+  const int gl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int g = blockIdx.x * 32 + gl;
+  const long long r0 = blockIdx.y * rows_per_chunk;
+  long long r1 = r0 + rows_per_chunk;
+  if (r1 > rows) r1 = rows;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (g < CG) {
+    for (long long row = r0 + rl; row < r1; row += 8) {
+      float v[8];
+      ffa_load8<T>(x + row * (long long)C + g * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][gl][e] = acc[e];
+  __syncthreads();
+  if (rl == 0 && g < CG) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v += red[r][gl][e];
+      partial[(long long)blockIdx.y * C + g * 8 + e] = v;
+    }
+  }
+}
+
+__global__ void column_sums_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int C, int chunks) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int k = 0; k < chunks; ++k) a += partial[(long long)k * C + c];
+  out[c] = a;
+}
+
+extern "C" long long ffa_column_sums_workspace_bytes(long long rows, int C) {
+  return (long long)ln_bwd_chunks(rows) * C * (long long)sizeof(float);
+}
+
+extern "C" int ffa_column_sums(int dtype, const void* x, float* out, long long rows, int C, void* workspace,
+                               long long workspace_bytes, hipStream_t stream) {
+  FFA_REQUIRE(x && out && rows > 0 && C > 0 && C % 8 == 0, "column_sums: bad arguments");
+  if (!workspace || workspace_bytes < ffa_column_sums_workspace_bytes(rows, C)) {
+    ffa_set_error("column_sums: workspace of %lld bytes needed", ffa_column_sums_workspace_bytes(rows, C));
+    return FFA_ERR_WORKSPACE;
+  }
+  const int chunks = ln_bwd_chunks(rows);
+  const long long rpc = (rows + chunks - 1) / chunks;
+  const dim3 grid((unsigned)((C / 8 + 31) / 32), (unsigned)chunks);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(column_sums_kernel<ffa_bf16>, grid, dim3(256), 0, stream, (const ffa_bf16*)x, (float*)workspace,
+                       rows, C, rpc);
+  else
+    hipLaunchKernelGGL(column_sums_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (float*)workspace, rows, C,
+                       rpc);
+  hipLaunchKernelGGL(column_sums_reduce_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream,
+                     (const float*)workspace, out, C, chunks);
+  return ffa_check_launch("column_sums");
 }

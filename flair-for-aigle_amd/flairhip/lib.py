@@ -78,8 +78,18 @@ SIGNATURES = {
     "ffa_mask_images": (_i, [_i, _p, _p, _i, _ll, _f, _p]),
     "ffa_linear": (_i, [_i, _p, _ll, _p, _p, _p, _ll, _p, _ll, _i, _i, _i, _i, _p]),
     "ffa_space_to_depth": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "ffa_layer_norm": (_i, [_i, _p, _p, _p, _p, _ll, _i, _f, _p]),
-    "ffa_patch_merge_norm": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "ffa_linear_ex": (_i, [_i, _p, _ll, _p, _p, _p, _ll, _p, _ll, _i, _i, _i, _i, _p, _ll, _p, _i, _p]),
+    "ffa_layer_norm": (_i, [_i, _p, _p, _p, _p, _p, _ll, _i, _f, _p]),
+    "ffa_patch_merge_norm": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "ffa_layer_norm_bwd_workspace_bytes": (_ll, [_ll, _i]),
+    "ffa_layer_norm_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _p, _ll, _p]),
+    "ffa_scale_rows": (_i, [_i, _p, _p, _p, _ll, _i, _i, _p]),
+    "ffa_column_sums_workspace_bytes": (_ll, [_ll, _i]),
+    "ffa_column_sums": (_i, [_i, _p, _p, _ll, _i, _p, _ll, _p]),
+    "ffa_patch_merge_norm_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _ll, _p]),
+    "ffa_window_attention_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "ffa_bilinear_slice_bwd": (_i, [_i, _p, _p] + [_i] * 9 + [_p]),
+    "ffa_adaptive_avg_pool_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ffa_window_attention": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "ffa_gelu": (_i, [_i, _p, _p, _ll, _p]),
     "ffa_adaptive_avg_pool": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p]),

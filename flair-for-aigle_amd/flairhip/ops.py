@@ -910,13 +910,16 @@ def mask_images_(x: torch.Tensor, pad: torch.Tensor, value: float = 0.0) -> torc
 # --------------------------------------------------------------------------------------------------
 # Swin-Transformer / UPerNet (csrc/transformer.hip, csrc/gemm.hip)
 
-ACT_NONE, ACT_GELU = 0, 1
+ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
-           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """nn.Linear on the last dimension of a bf16 token tensor [..., K]: act(x w^T + bias) + residual.
-    w: bf16 [N, K] (nn.Linear.weight's layout), bias f32 [N]."""
+           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+           aux: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
+           rows_per_scale: int = 0) -> torch.Tensor:
+    """nn.Linear on the last dimension of a bf16 token tensor [..., K]: act(x w^T + bias) * row_scale + residual.
+    w: bf16 [N, K] (nn.Linear.weight's layout), bias f32 [N].  aux ([..., N] bf16): with ACT_GELU it RECEIVES the
+    pre-activation, with ACT_DGELU it supplies it (out = (x w^T) * gelu'(aux)).  row_scale f32 [M / rows_per_scale]."""
     if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
         raise ValueError("linear: bf16 operands only (f32 parity mode goes through conv2d 1x1)")
     if not x.is_contiguous() or not w.is_contiguous():
@@ -928,10 +931,15 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     M = x.numel() // K
     if out is None:
         out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
-    if residual is not None and (residual.shape != out.shape or not residual.is_contiguous()):
-        raise ValueError("linear: residual must be contiguous and shaped like the output")
-    _l.check(_l.load().ffa_linear(_dt(x), x.data_ptr(), K, w.data_ptr(), _ptr(bias), _ptr(residual), N, out.data_ptr(),
-                                  N, M, K, N, act, _stream()), "linear")
+    for name, t in (("residual", residual), ("aux", aux)):
+        if t is not None and (t.shape != out.shape or not t.is_contiguous() or t.dtype != x.dtype):
+            raise ValueError(f"linear: {name} must be contiguous bf16 and shaped like the output")
+    if row_scale is not None and (row_scale.dtype != torch.float32 or rows_per_scale <= 0 or
+                                  row_scale.numel() * rows_per_scale < M):
+        raise ValueError("linear: row_scale must be f32 with one entry per rows_per_scale rows")
+    _l.check(_l.load().ffa_linear_ex(_dt(x), x.data_ptr(), K, w.data_ptr(), _ptr(bias), _ptr(residual), N,
+                                     out.data_ptr(), N, M, K, N, act, _ptr(aux), N, _ptr(row_scale), rows_per_scale,
+                                     _stream()), "linear")
     return out
 
 
@@ -947,24 +955,60 @@ def space_to_depth(x: torch.Tensor, ps: int) -> torch.Tensor:
     return out
 
 
-def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+               stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.LayerNorm over the last dimension; ``stats`` (f32 [rows, 2]) receives (mean, rstd) for layer_norm_bwd"""
     if not x.is_contiguous():
         raise ValueError("layer_norm: input must be contiguous")
     C = x.shape[-1]
     out = torch.empty_like(x)
     _l.check(_l.load().ffa_layer_norm(_dt(x), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                      x.numel() // C, C, eps, _stream()), "layer_norm")
+                                      _ptr(stats), x.numel() // C, C, eps, _stream()), "layer_norm")
     return out
 
 
-def patch_merge_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+def layer_norm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, stats: torch.Tensor,
+                   dres: Optional[torch.Tensor] = None):
+    """-> (dx [+ dres], dgamma f32, dbeta f32)"""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    lib = _l.load()
+    dx = torch.empty_like(x)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty(C, dtype=torch.float32, device=x.device)
+    nb = lib.ffa_layer_norm_bwd_workspace_bytes(rows, C)
+    ws = workspace(nb, x.device, "ln_bwd")
+    _l.check(lib.ffa_layer_norm_bwd(_dt(x), x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), stats.data_ptr(),
+                                    _ptr(dres), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, C, ws.data_ptr(), ws.numel(),
+                                    _stream()), "layer_norm_bwd")
+    return dx, dg, db
+
+
+def patch_merge_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+                     stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """PatchMerging's gather + LayerNorm(4C): [B,H,W,C] -> [B,H/2,W/2,4C]"""
     _chk_nhwc(x, "patch_merge input")
     B, H, W, C = x.shape
     out = torch.empty((B, H // 2, W // 2, 4 * C), dtype=x.dtype, device=x.device)
-    _l.check(_l.load().ffa_patch_merge_norm(_dt(x), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B,
-                                            H, W, C, eps, _stream()), "patch_merge_norm")
+    _l.check(_l.load().ffa_patch_merge_norm(_dt(x), x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                            _ptr(stats), B, H, W, C, eps, _stream()), "patch_merge_norm")
     return out
+
+
+def patch_merge_norm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, stats: torch.Tensor):
+    """x [B,H,W,C] (the forward's input), dy [B,H/2,W/2,4C] -> (dx [B,H,W,C], dgamma, dbeta)"""
+    B, H, W, C = x.shape
+    rows = B * (H // 2) * (W // 2)
+    lib = _l.load()
+    dx = torch.empty_like(x)
+    dg = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+    db = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+    nb = lib.ffa_layer_norm_bwd_workspace_bytes(rows, 4 * C)
+    ws = workspace(nb, x.device, "ln_bwd")
+    _l.check(lib.ffa_patch_merge_norm_bwd(_dt(x), x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), stats.data_ptr(),
+                                          dx.data_ptr(), dg.data_ptr(), db.data_ptr(), B, H, W, C, ws.data_ptr(),
+                                          ws.numel(), _stream()), "patch_merge_norm_bwd")
+    return dx, dg, db
 
 
 def window_attention(qkv: torch.Tensor, qkv_bias: torch.Tensor, table: torch.Tensor, heads: int, ws: int, shift: int,
@@ -1014,4 +1058,68 @@ def bilinear_slice(x: torch.Tensor, out_hw: Tuple[int, int], out: Optional[torch
     _l.check(_l.load().ffa_bilinear_slice(_dt(x), x.data_ptr(), _ptr(addend), out.data_ptr(), B, Hi, Wi, Ho, Wo, C,
                                           out.shape[-1], offset, 1 if align_corners else 0, _stream()),
              "bilinear_slice")
+    return out
+
+
+def window_attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, qkv_bias: torch.Tensor, table: torch.Tensor, heads: int,
+                         ws: int, shift: int, scale: float):
+    """-> (dqkv [B,H,W,3C], dtable f32 [(2ws-1)^2, heads], dbias_pad f32 [3C]: what reaches the qkv bias through the
+    padding tokens of the window grid)"""
+    _chk_nhwc(qkv, "window_attention_bwd qkv")
+    _chk_nhwc(dout, "window_attention_bwd dout")
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    if dout.shape != (B, H, W, C) or dout.dtype != qkv.dtype:
+        raise ValueError("window_attention_bwd: dout must be [B,H,W,C] in the dtype of qkv")
+    dqkv = torch.empty_like(qkv)
+    dtable = torch.zeros_like(table)
+    dbias = torch.zeros(C3, dtype=torch.float32, device=qkv.device)
+    _l.check(_l.load().ffa_window_attention_bwd(_dt(qkv), qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(),
+                                                qkv_bias.data_ptr(), table.data_ptr(), dtable.data_ptr(),
+                                                dbias.data_ptr(), B, H, W, C, heads, ws, shift, scale, _stream()),
+             "window_attention_bwd")
+    return dqkv, dtable, dbias
+
+
+def bilinear_slice_bwd(dy: torch.Tensor, in_hw: Tuple[int, int], channels: int, offset: int = 0,
+                       align_corners: bool = False) -> torch.Tensor:
+    """gradient of bilinear_slice w.r.t. its input: dy [B,Ho,Wo,pitch] (slice [offset, offset+channels)) -> [B,Hi,Wi,channels]"""
+    _chk_nhwc(dy, "bilinear_slice_bwd dy")
+    B, Ho, Wo, P = dy.shape
+    Hi, Wi = in_hw
+    dx = torch.empty((B, Hi, Wi, channels), dtype=dy.dtype, device=dy.device)
+    _l.check(_l.load().ffa_bilinear_slice_bwd(_dt(dy), dy.data_ptr(), dx.data_ptr(), B, Hi, Wi, Ho, Wo, channels, P,
+                                              offset, 1 if align_corners else 0, _stream()), "bilinear_slice_bwd")
+    return dx
+
+
+def adaptive_avg_pool_bwd(dy: torch.Tensor, in_hw: Tuple[int, int]) -> torch.Tensor:
+    _chk_nhwc(dy, "adaptive_avg_pool_bwd dy")
+    B, S, _, C = dy.shape
+    H, W = in_hw
+    dx = torch.empty((B, H, W, C), dtype=dy.dtype, device=dy.device)
+    _l.check(_l.load().ffa_adaptive_avg_pool_bwd(_dt(dy), dy.data_ptr(), dx.data_ptr(), B, H, W, C, S, _stream()),
+             "adaptive_avg_pool_bwd")
+    return dx
+
+
+def scale_rows(x: torch.Tensor, row_scale: torch.Tensor, rows_per_scale: int) -> torch.Tensor:
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    _l.check(_l.load().ffa_scale_rows(_dt(x), x.data_ptr(), out.data_ptr(), row_scale.data_ptr(), x.numel() // C, C,
+                                      rows_per_scale, _stream()), "scale_rows")
+    return out
+
+
+def column_sums(x: torch.Tensor) -> torch.Tensor:
+    """f32 [C]: sum over every row of a contiguous [..., C] tensor (nn.Linear's bias gradient)"""
+    if not x.is_contiguous():
+        raise ValueError("column_sums: input must be contiguous")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    lib = _l.load()
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = workspace(lib.ffa_column_sums_workspace_bytes(rows, C), x.device, "colsum")
+    _l.check(lib.ffa_column_sums(_dt(x), x.data_ptr(), out.data_ptr(), rows, C, ws.data_ptr(), ws.numel(), _stream()),
+             "column_sums")
     return out

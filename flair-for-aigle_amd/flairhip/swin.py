@@ -20,8 +20,14 @@ Arithmetic (all NHWC, a token = a pixel of the stage's map):
 bf16 mode uses the hand-written token GEMM (csrc/gemm.hip); the f32 parity mode runs the same layers through the f32
 1x1 convolution kernel and a separate GELU pass.
 
-Scope: evaluation mode (zonal inference, validation, predict).  Training this architecture needs the backward kernels of
-LayerNorm / window attention / GELU / adaptive pooling, which do not exist yet: NotImplementedError, never a torch fallback.
+Training (bf16 only): every block half / merging / embedding / decoder resampling step is one autograd node whose
+backward runs on the same library -- input gradients through the token GEMM with the TRANSPOSED weight (gelu' of the kept
+pre-activation and the DropPath factor in its epilogue), weight gradients through the 1x1 instance of ffa_conv_wgrad
+(deterministic split-K over the tokens), bias gradients through ffa_channel_sums, ffa_layer_norm_bwd (with the residual
+gradient added in the same pass), ffa_window_attention_bwd, ffa_bilinear_slice_bwd, ffa_adaptive_avg_pool_bwd.  timm's
+DropPath (stochastic depth, drop_path_rate = 0.1 by default, linearly increasing over the blocks) is the per-sample
+row scale of the residual GEMMs.  The f32 parity mode covers the evaluation forward only (the attention backward is a
+bf16 MFMA kernel): training in fp32 raises NotImplementedError, never a torch fallback.
 """
 from __future__ import annotations
 
@@ -165,14 +171,230 @@ def _apply_linear(x: torch.Tensor, operand, n_out: int, act: int = ops.ACT_NONE,
     return y
 
 
+# --------------------------------------------------------------------------------------------------
+# training: autograd nodes (bf16)
+
+def _wt(cache: _Operands, tag: str, weight: torch.Tensor):
+    """(W, W^T) in bf16, rebuilt when the parameter changes: forward operand [N,K] and input-gradient operand [K,N]"""
+    def build():
+        w = weight.detach().to(torch.bfloat16).contiguous()
+        return w, w.t().contiguous()
+    return cache.get(tag + ":wt", (weight,), torch.bfloat16, build)
+
+
+def _wgrad(x: torch.Tensor, dy: torch.Tensor, n_out: int, n_in: int) -> torch.Tensor:
+    """dW [n_out, n_in] f32 = dy^T x over all tokens (ffa_conv_wgrad's 1x1 instance, deterministic split-K)"""
+    x4 = x if x.dim() == 4 else x.reshape(1, 1, -1, x.shape[-1])
+    d4 = dy if dy.dim() == 4 else dy.reshape(1, 1, -1, dy.shape[-1])
+    return ops.conv_wgrad(x4, d4, n_out, n_in, 1, 1, 1, 0).view(n_out, n_in)
+
+
+def _colsum(dy: torch.Tensor) -> torch.Tensor:
+    return ops.column_sums(dy)
+
+
+def _drop_path_scale(rate: float, batch: int, device) -> Optional[torch.Tensor]:
+    """timm DropPath(drop_prob, scale_by_keep=True): per sample 0 or 1 / keep_prob"""
+    if rate <= 0.0:
+        return None
+    keep = 1.0 - rate
+    return torch.empty(batch, dtype=torch.float32, device=device).bernoulli_(keep).div_(keep)
+
+
+class _AttnHalf(torch.autograd.Function):
+    """x + DropPath(proj(window_attention(qkv(LayerNorm(x)))))  -- the first half of a SwinTransformerBlock"""
+
+    @staticmethod
+    def forward(ctx, x, g1, b1, wqkv, bqkv, table, wproj, bproj, enc, blk, tag, rs):
+        C = blk.dim
+        rows = x.numel() // C
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        h = ops.layer_norm(x, g1.detach(), b1.detach(), stats=stats)
+        wq, _ = _wt(enc._ops, tag + "qkv", wqkv)
+        qkv = ops.linear(h, wq, bqkv.detach())
+        scale = float((C // blk.heads) ** -0.5)
+        att = ops.window_attention(qkv, bqkv.detach(), table.detach().contiguous(), blk.heads, blk.ws, blk.shift, scale)
+        wp, _ = _wt(enc._ops, tag + "proj", wproj)
+        rps = x.shape[1] * x.shape[2]
+        y = ops.linear(att, wp, bproj.detach(), residual=x, row_scale=rs, rows_per_scale=rps if rs is not None else 0)
+        ctx.enc, ctx.blk, ctx.tag, ctx.scale, ctx.rps = enc, blk, tag, scale, rps
+        ctx.save_for_backward(x, stats, h, qkv, att, g1, wqkv, bqkv, table, wproj, rs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, h, qkv, att, g1, wqkv, bqkv, table, wproj, rs = ctx.saved_tensors
+        enc, blk, tag = ctx.enc, ctx.blk, ctx.tag
+        C = blk.dim
+        dy = dy.contiguous()
+        dys = dy if rs is None else ops.scale_rows(dy, rs, ctx.rps)
+        _, wpt = _wt(enc._ops, tag + "proj", wproj)
+        datt = ops.linear(dys, wpt)
+        dwp = _wgrad(att, dys, C, C)
+        dbp = _colsum(dys)
+        dqkv, dtable, dbpad = ops.window_attention_bwd(qkv, datt, bqkv.detach(), table.detach().contiguous(), blk.heads,
+                                                       blk.ws, blk.shift, ctx.scale)
+        _, wqt = _wt(enc._ops, tag + "qkv", wqkv)
+        dh = ops.linear(dqkv, wqt)
+        dwq = _wgrad(h, dqkv, 3 * C, C)
+        dbq = _colsum(dqkv) + dbpad
+        dx, dg1, db1 = ops.layer_norm_bwd(x, dh, g1.detach(), stats, dres=dy)
+        return dx, dg1, db1, dwq, dbq, dtable, dwp, dbp, None, None, None, None
+
+
+class _MlpHalf(torch.autograd.Function):
+    """x + DropPath(fc2(gelu(fc1(LayerNorm(x)))))  -- the second half of a SwinTransformerBlock"""
+
+    @staticmethod
+    def forward(ctx, x, g2, b2, w1, bb1, w2, bb2, enc, blk, tag, rs):
+        C = blk.dim
+        rows = x.numel() // C
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        h = ops.layer_norm(x, g2.detach(), b2.detach(), stats=stats)
+        w1b, _ = _wt(enc._ops, tag + "fc1", w1)
+        u = torch.empty(x.shape[:-1] + (4 * C,), dtype=x.dtype, device=x.device)
+        a = ops.linear(h, w1b, bb1.detach(), act=ops.ACT_GELU, aux=u)
+        w2b, _ = _wt(enc._ops, tag + "fc2", w2)
+        rps = x.shape[1] * x.shape[2]
+        y = ops.linear(a, w2b, bb2.detach(), residual=x, row_scale=rs, rows_per_scale=rps if rs is not None else 0)
+        ctx.enc, ctx.blk, ctx.tag, ctx.rps = enc, blk, tag, rps
+        ctx.save_for_backward(x, stats, h, u, a, g2, w1, w2, rs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, h, u, a, g2, w1, w2, rs = ctx.saved_tensors
+        enc, blk, tag = ctx.enc, ctx.blk, ctx.tag
+        C = blk.dim
+        dy = dy.contiguous()
+        dys = dy if rs is None else ops.scale_rows(dy, rs, ctx.rps)
+        _, w2t = _wt(enc._ops, tag + "fc2", w2)
+        du = ops.linear(dys, w2t, act=ops.ACT_DGELU, aux=u)  # (dys W2) * gelu'(u)
+        dw2 = _wgrad(a, dys, C, 4 * C)
+        db2 = _colsum(dys)
+        _, w1t = _wt(enc._ops, tag + "fc1", w1)
+        dh = ops.linear(du, w1t)
+        dw1 = _wgrad(h, du, 4 * C, C)
+        db1 = _colsum(du)
+        dx, dg, db = ops.layer_norm_bwd(x, dh, g2.detach(), stats, dres=dy)
+        return dx, dg, db, dw1, db1, dw2, db2, None, None, None, None
+
+
+class _PatchMerge(torch.autograd.Function):
+    """reduction(LayerNorm(2x2 gather))"""
+
+    @staticmethod
+    def forward(ctx, x, g, b, wred, enc, tag):
+        B, H, W, C = x.shape
+        stats = torch.empty((B * (H // 2) * (W // 2), 2), dtype=torch.float32, device=x.device)
+        m = ops.patch_merge_norm(x, g.detach(), b.detach(), stats=stats)
+        wr, _ = _wt(enc._ops, tag, wred)
+        y = ops.linear(m, wr)
+        ctx.enc, ctx.tag = enc, tag
+        ctx.save_for_backward(x, stats, m, g, wred)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, m, g, wred = ctx.saved_tensors
+        dy = dy.contiguous()
+        _, wrt = _wt(ctx.enc._ops, ctx.tag, wred)
+        dm = ops.linear(dy, wrt)
+        dw = _wgrad(m, dy, wred.shape[0], wred.shape[1])
+        dx, dg, db = ops.patch_merge_norm_bwd(x, dm, g.detach(), stats)
+        return dx, dg, db, dw, None, None
+
+
+class _PatchEmbed(torch.autograd.Function):
+    """LayerNorm(Conv2d(k = s = patch)(x)) on the NHWC input tensor (which needs no gradient)"""
+
+    @staticmethod
+    def forward(ctx, x, wproj, bproj, g, b, enc):
+        ps, cp = enc.patch, x.shape[-1]
+        dim, cin = wproj.shape[0], wproj.shape[1]
+        w2 = torch.zeros(dim, ps, ps, cp, dtype=torch.float32, device=x.device)
+        w2[..., :cin] = wproj.detach().permute(0, 2, 3, 1)
+        s2d = ops.space_to_depth(x, ps)
+        t = ops.linear(s2d, w2.reshape(dim, -1).to(torch.bfloat16), bproj.detach())
+        stats = torch.empty((t.numel() // dim, 2), dtype=torch.float32, device=x.device)
+        y = ops.layer_norm(t, g.detach(), b.detach(), stats=stats)
+        ctx.geom = (ps, cp, dim, cin)
+        ctx.save_for_backward(s2d, t, stats, g)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        s2d, t, stats, g = ctx.saved_tensors
+        ps, cp, dim, cin = ctx.geom
+        dt, dg, db = ops.layer_norm_bwd(t, dy.contiguous(), g.detach(), stats)
+        dw2 = _wgrad(s2d, dt, dim, ps * ps * cp)
+        dw = dw2.view(dim, ps, ps, cp)[..., :cin].permute(0, 3, 1, 2).contiguous()
+        dbias = _colsum(dt)
+        return None, dw, dbias, dg, db, None
+
+
+class _AdaptivePool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size):
+        ctx.hw = (x.shape[1], x.shape[2])
+        return ops.adaptive_avg_pool(x, size)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.adaptive_avg_pool_bwd(dy.contiguous(), ctx.hw), None
+
+
+class _ResizeCat(torch.autograd.Function):
+    """cat([bilinear(t, out_hw) for t in tensors], channel) assembled in place (align_corners=False)"""
+
+    @staticmethod
+    def forward(ctx, out_hw, *tensors):
+        B = tensors[0].shape[0]
+        widths = [t.shape[-1] for t in tensors]
+        out = torch.empty((B, out_hw[0], out_hw[1], sum(widths)), dtype=tensors[0].dtype, device=tensors[0].device)
+        off = 0
+        for t, c in zip(tensors, widths):
+            ops.bilinear_slice(t, out_hw, out=out, offset=off)
+            off += c
+        ctx.shapes = [(t.shape[1], t.shape[2], t.shape[3]) for t in tensors]
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        grads, off = [], 0
+        for i, (h, w, c) in enumerate(ctx.shapes):
+            grads.append(ops.bilinear_slice_bwd(dy, (h, w), c, offset=off) if ctx.needs_input_grad[i + 1] else None)
+            off += c
+        return (None, *grads)
+
+
+class _ResizeAdd(torch.autograd.Function):
+    """bilinear(x, out_hw, align_corners) (+ addend)"""
+
+    @staticmethod
+    def forward(ctx, x, addend, out_hw, align):
+        ctx.hw, ctx.align, ctx.has_add = (x.shape[1], x.shape[2]), align, addend is not None
+        return ops.bilinear_slice(x, out_hw, addend=addend, align_corners=align)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = ops.bilinear_slice_bwd(dy, ctx.hw, dy.shape[-1], align_corners=ctx.align) if ctx.needs_input_grad[0] else None
+        return dx, (dy if ctx.has_add else None), None, None
+
+
 class HipSwinEncoder(nn.Module):
     """smp's TimmUniversalEncoder over a timm Swin (features_only): forward(x_nhwc) ->
     [x, 0-channel placeholder at stride 2, f4, f8, f16, f32] (NHWC); ``out_channels`` = [in, 0, C, 2C, 4C, 8C]
     (the reference strips the two leading entries itself: flair_model.py:302-306, 506-518)."""
 
-    def __init__(self, name: str, in_channels: int = 3, img_size: int = 512):
+    def __init__(self, name: str, in_channels: int = 3, img_size: int = 512, drop_path_rate: float = 0.1):
         super().__init__()
         dim, depths, heads, ws, patch = parse_swin_name(name)
+        # timm: SwinTransformer(drop_path_rate=0.1), the rate of block i = linspace(0, rate, sum(depths))[i]
+        total = sum(depths)
+        self.drop_path_rates = [drop_path_rate * i / max(total - 1, 1) for i in range(total)]
         if (dim // heads[0]) != 32:
             raise NotImplementedError("window attention kernels are built for a head dimension of 32")
         if ws > 12:
@@ -234,27 +456,49 @@ class HipSwinEncoder(nn.Module):
                              residual=x, out=x)
 
     def forward(self, x: torch.Tensor) -> List[torch.Tensor]:
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("HipSwinEncoder: evaluation-mode forward only (no backward kernels for LayerNorm / "
-                                      "window attention / GELU yet); call .eval() or run under torch.no_grad()")
         if not x.is_cuda:
             raise RuntimeError("HipSwinEncoder runs on the MI355X only (no CPU path in the product)")
         B, H, W, _ = x.shape
         if H % (self.patch * 8) or W % (self.patch * 8):
             raise ValueError(f"input {H}x{W} must be a multiple of {self.patch * 8}")
+        train = self.training and torch.is_grad_enabled()
+        if train and x.dtype != torch.bfloat16:
+            raise NotImplementedError("HipSwinEncoder trains in bf16 only (the window-attention backward is a bf16 MFMA "
+                                      "kernel); the fp32 parity mode covers the evaluation forward")
         feats = [x, x.new_empty((B, H // 2, W // 2, 0))]
-        t = self._patch_embed(x)
+        m = self.model
+        if train:
+            pe = m.patch_embed
+            t = _PatchEmbed.apply(x, pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, self)
+        else:
+            t = self._patch_embed(x)
+        k = 0
         for i in range(4):
-            stage = getattr(self.model, f"layers_{i}")
+            stage = getattr(m, f"layers_{i}")
             if i > 0:
                 ds = stage.downsample
-                m = ops.patch_merge_norm(t, ds.norm.weight.detach(), ds.norm.bias.detach())
-                t = _apply_linear(m, _lin_operand(self._ops, f"s{i}red", ds.reduction.weight, None, t.dtype), self.dims[i])
+                if train:
+                    t = _PatchMerge.apply(t, ds.norm.weight, ds.norm.bias, ds.reduction.weight, self, f"s{i}red")
+                else:
+                    mm = ops.patch_merge_norm(t, ds.norm.weight.detach(), ds.norm.bias.detach())
+                    t = _apply_linear(mm, _lin_operand(self._ops, f"s{i}red", ds.reduction.weight, None, t.dtype),
+                                      self.dims[i])
             for j, blk in enumerate(stage.blocks):
                 if min(t.shape[1], t.shape[2]) < blk.ws:
                     raise ValueError(f"stage {i} map {t.shape[1]}x{t.shape[2]} is smaller than the window {blk.ws} the "
                                      f"encoder was built for (img_size={self.img_size})")
-                t = self._block(t, blk, f"s{i}b{j}")
+                tag = f"s{i}b{j}"
+                if train:
+                    a, rate = blk.attn, self.drop_path_rates[k]
+                    t = _AttnHalf.apply(t, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias,
+                                        a.relative_position_bias_table, a.proj.weight, a.proj.bias, self, blk, tag,
+                                        _drop_path_scale(rate, B, t.device))
+                    t = _MlpHalf.apply(t, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+                                       blk.mlp.fc2.weight, blk.mlp.fc2.bias, self, blk, tag,
+                                       _drop_path_scale(rate, B, t.device))
+                else:
+                    t = self._block(t, blk, tag)
+                k += 1
             feats.append(t)
         return feats
 
@@ -292,9 +536,27 @@ class HipUPerNetDecoder(nn.Module):
             if isinstance(m, hnn.HipConv2d):
                 nn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="relu")
 
+    def _forward_train(self, *features: torch.Tensor) -> torch.Tensor:
+        """the same graph through autograd nodes (training-mode BatchNorm inside conv_bn_act)"""
+        H, W = features[0].shape[1], features[0].shape[2]
+        target = (H // 4, W // 4)
+        feats = list(features[1:])[::-1]
+        x = feats[0]
+        h, w = x.shape[1], x.shape[2]
+        pooled = [hnn.conv_bn_act(_AdaptivePool.apply(x, s), blk[1][0], blk[1][1], relu=True)
+                  for s, blk in zip(self.sizes, self.psp.blocks)]
+        cat = _ResizeCat.apply((h, w), x, *pooled)
+        fpn = [hnn.conv_bn_act(cat, self.psp.out_conv[0], self.psp.out_conv[1], relu=True)]
+        for f, stage in zip(feats[1:], self.fpn_stages):
+            size = (f.shape[1], f.shape[2])
+            lat = hnn.conv_bn_act(f, stage.skip_conv[0], stage.skip_conv[1], relu=True) if f.shape[-1] != 0 else None
+            fpn.append(_ResizeAdd.apply(fpn[-1], lat, size, False))
+        wide = _ResizeCat.apply(target, *fpn)
+        return hnn.conv_bn_act(wide, self.fpn_bottleneck[0], self.fpn_bottleneck[1], relu=True)
+
     def forward(self, *features: torch.Tensor) -> torch.Tensor:
         if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("HipUPerNetDecoder: evaluation-mode forward only; call .eval()")
+            return self._forward_train(*features)
         H, W = features[0].shape[1], features[0].shape[2]
         target = (H // 4, W // 4)
         feats = list(features[1:])[::-1]
@@ -335,16 +597,20 @@ class HipUPerNetHead(nn.Sequential):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y = hnn.conv_bias(x, self[0])
         if self.upsampling > 1:
-            y = ops.bilinear_slice(y, (y.shape[1] * self.upsampling, y.shape[2] * self.upsampling), align_corners=True)
+            size = (y.shape[1] * self.upsampling, y.shape[2] * self.upsampling)
+            if torch.is_grad_enabled() and y.requires_grad:
+                return _ResizeAdd.apply(y, None, size, True)
+            y = ops.bilinear_slice(y, size, align_corners=True)
         return y
 
 
 class SwinUPerNet(nn.Module):
     """Counterpart of smp.create_model('upernet', 'tu-swin_...', classes=..., in_channels=..., img_size=...)."""
 
-    def __init__(self, encoder_name: str, in_channels: int = 3, classes: int = 1, img_size: int = 512):
+    def __init__(self, encoder_name: str, in_channels: int = 3, classes: int = 1, img_size: int = 512,
+                 drop_path_rate: float = 0.1):
         super().__init__()
-        self.encoder = HipSwinEncoder(encoder_name, in_channels, img_size)
+        self.encoder = HipSwinEncoder(encoder_name, in_channels, img_size, drop_path_rate)
         self.decoder = HipUPerNetDecoder(self.encoder.out_channels)
         self.segmentation_head = HipUPerNetHead(64, classes)
 

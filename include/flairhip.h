@@ -177,20 +177,44 @@ int ffa_mask_images(int dtype, void* x, const unsigned char* pad, int N, long lo
  * w is nn.Linear.weight's own [N][K] layout in bf16.  bf16 only (the f32 parity mode runs ffa_conv2d 1x1). */
 int ffa_linear(int dtype, const void* a, long long lda, const void* w, const float* bias, const void* residual,
                long long ldr, void* out, long long ldc, int M, int K, int N, int act, ffa_stream_t stream);
+/* The same GEMM with the training-time epilogues: act = FFA_ACT_GELU with `aux` != NULL also stores the (bf16) pre-activation
+ * to aux [M][ldaux] (Mlp.fc1, kept for the backward pass); act = FFA_ACT_DGELU multiplies the result by gelu'(aux) (the input
+ * gradient of Mlp.fc2 carried through the activation); row_scale[m / rows_per_scale] multiplies the result before the
+ * residual add (timm's DropPath: 0 or 1 / keep_prob per sample). */
+#define FFA_ACT_DGELU 2
+int ffa_linear_ex(int dtype, const void* a, long long lda, const void* w, const float* bias, const void* residual,
+                  long long ldr, void* out, long long ldc, int M, int K, int N, int act, void* aux, long long ldaux,
+                  const float* row_scale, int rows_per_scale, ffa_stream_t stream);
 /* PatchEmbed's Conv2d(kernel = stride = ps) as a gather: out[b][y][x][(dy*ps + dx)*C + c] = in[b][y*ps+dy][x*ps+dx][c] */
 int ffa_space_to_depth(int dtype, const void* in, void* out, int B, int Ho, int Wo, int C, int ps, ffa_stream_t stream);
-/* nn.LayerNorm(C) over rows of C contiguous channels */
-int ffa_layer_norm(int dtype, const void* x, void* y, const float* gamma, const float* beta, long long rows, int C,
-                   float eps, ffa_stream_t stream);
+/* nn.LayerNorm(C) over rows of C contiguous channels; stats (nullable) receives (mean, rstd) per row for the backward pass */
+int ffa_layer_norm(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* stats, long long rows,
+                   int C, float eps, ffa_stream_t stream);
 /* PatchMerging's 2x2 gather + nn.LayerNorm(4C): x [B][H][W][C] -> y [B][H/2][W/2][4C] */
-int ffa_patch_merge_norm(int dtype, const void* x, void* y, const float* gamma, const float* beta, int B, int H, int W,
-                         int C, float eps, ffa_stream_t stream);
+int ffa_patch_merge_norm(int dtype, const void* x, void* y, const float* gamma, const float* beta, float* stats, int B,
+                         int H, int W, int C, float eps, ffa_stream_t stream);
+/* backward of the two: dx, dgamma, dbeta (f32) from x (the forward's input), dy and the forward's row statistics;
+ * deterministic (chunk partials in the workspace, summed in a fixed order) */
+long long ffa_layer_norm_bwd_workspace_bytes(long long rows, int C);
+int ffa_layer_norm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* stats,
+                       const void* dres /* nullable: added to dx (the residual around the normalised branch) */, void* dx,
+                       float* dgamma, float* dbeta, long long rows, int C, void* workspace, long long workspace_bytes,
+                       ffa_stream_t stream);
+int ffa_patch_merge_norm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* stats, void* dx,
+                             float* dgamma, float* dbeta, int B, int H, int W, int C, void* workspace,
+                             long long workspace_bytes, ffa_stream_t stream);
 /* SwinTransformerBlock._attn without the two projections: cyclic shift, padding to the window grid, window partition,
  * softmax(scale q k^T + relative position bias + shift mask) v, window reverse, crop, un-shift -- by index arithmetic on
  * qkv [B][H][W][3C] (channel = which*C + head*32 + d); qkv_bias [3C] is what a padding token projects to;
  * table [(2 ws - 1)^2][heads] is relative_position_bias_table */
 int ffa_window_attention(int dtype, const void* qkv, void* out, const float* qkv_bias, const float* table, int B, int H,
                          int W, int C, int heads, int ws, int shift, float scale, ffa_stream_t stream);
+/* backward of ffa_window_attention (bf16): dqkv [B][H][W][3C] from qkv and dout [B][H][W][C]; dtable [(2 ws - 1)^2][heads]
+ * and dbias_pad [3C] (gradient reaching the qkv bias through the padding tokens) are ACCUMULATED with f32 atomics and
+ * must be zeroed by the caller */
+int ffa_window_attention_bwd(int dtype, const void* qkv, const void* dout, void* dqkv, const float* qkv_bias,
+                             const float* table, float* dtable, float* dbias_pad, int B, int H, int W, int C, int heads,
+                             int ws, int shift, float scale, ffa_stream_t stream);
 /* nn.GELU() (erf form), elementwise; n a multiple of 8 */
 int ffa_gelu(int dtype, const void* x, void* y, long long n, ffa_stream_t stream);
 /* nn.AdaptiveAvgPool2d(S) of smp's PSPModule: x [B][H][W][C] -> y [B][S][S][C] */
@@ -199,6 +223,18 @@ int ffa_adaptive_avg_pool(int dtype, const void* x, void* y, int B, int H, int W
  * plus an optional dense addend [B][Ho][Wo][C] (FPNBlock: upsample + lateral) */
 int ffa_bilinear_slice(int dtype, const void* x, const void* addend, void* y, int B, int Hi, int Wi, int Ho, int Wo,
                        int C, int y_pitch, int y_off, int align_corners, ffa_stream_t stream);
+
+/* y[m] = x[m] * row_scale[m / rows_per_scale] (DropPath factor on a gradient ahead of the weight / bias reductions) */
+int ffa_scale_rows(int dtype, const void* x, void* y, const float* row_scale, long long rows, int C, int rows_per_scale,
+                   ffa_stream_t stream);
+/* out[c] = sum_m x[m][c] (f32): nn.Linear's bias gradient, any width; deterministic */
+long long ffa_column_sums_workspace_bytes(long long rows, int C);
+int ffa_column_sums(int dtype, const void* x, float* out, long long rows, int C, void* workspace,
+                    long long workspace_bytes, ffa_stream_t stream);
+/* backward of ffa_bilinear_slice w.r.t. x (the addend's gradient is the slice itself) and of ffa_adaptive_avg_pool */
+int ffa_bilinear_slice_bwd(int dtype, const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int y_pitch,
+                           int y_off, int align_corners, ffa_stream_t stream);
+int ffa_adaptive_avg_pool_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int C, int S, ffa_stream_t stream);
 
 /* ---- BatchNorm2d + ReLU + residual, MaxPool2d(3,2,1) (smp ResNet-34 encoder / UnetDecoder blocks;
  *      SURVEY.md Appendix C) ----------------------------------------------------------------------- */

@@ -125,9 +125,26 @@ class Mlp(nn.Module):
         return self.fc2(F.gelu(self.fc1(x)))
 
 
-class SwinBlock(nn.Module):
-    def __init__(self, dim: int, resolution: Tuple[int, int], heads: int, ws: int, shift: int):
+class DropPath(nn.Module):
+    """timm layers/drop.py: stochastic depth per sample, kept samples scaled by 1 / keep_prob (training mode only)"""
+
+    def __init__(self, drop_prob: float = 0.0):
         super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        return x * mask.div_(keep)
+
+
+class SwinBlock(nn.Module):
+    def __init__(self, dim: int, resolution: Tuple[int, int], heads: int, ws: int, shift: int, drop_path: float = 0.0):
+        super().__init__()
+        self.drop_path1 = DropPath(drop_path)
+        self.drop_path2 = DropPath(drop_path)
         # a window never exceeds the map; a map that fits one window is not shifted
         self.ws = min(ws, min(resolution))
         self.shift = 0 if min(resolution) <= ws else shift
@@ -155,9 +172,9 @@ class SwinBlock(nn.Module):
 
     def forward(self, x):
         B, H, W, C = x.shape
-        x = x + self._attn(self.norm1(x))
+        x = x + self.drop_path1(self._attn(self.norm1(x)))
         x = x.reshape(B, -1, C)
-        x = x + self.mlp(self.norm2(x))
+        x = x + self.drop_path2(self.mlp(self.norm2(x)))
         return x.reshape(B, H, W, C)
 
 
@@ -176,11 +193,13 @@ class PatchMerging(nn.Module):
 
 
 class SwinStage(nn.Module):
-    def __init__(self, dim_in: int, dim: int, resolution, depth: int, heads: int, ws: int, downsample: bool):
+    def __init__(self, dim_in: int, dim: int, resolution, depth: int, heads: int, ws: int, downsample: bool,
+                 drop_path=None):
         super().__init__()
         self.downsample = PatchMerging(dim_in) if downsample else nn.Identity()
+        dp = drop_path if drop_path is not None else [0.0] * depth
         self.blocks = nn.Sequential(*[
-            SwinBlock(dim, resolution, heads, ws, 0 if i % 2 == 0 else ws // 2) for i in range(depth)])
+            SwinBlock(dim, resolution, heads, ws, 0 if i % 2 == 0 else ws // 2, dp[i]) for i in range(depth)])
 
     def forward(self, x):
         return self.blocks(self.downsample(x))
@@ -200,17 +219,20 @@ class SwinFeatures(nn.Module):
     """timm.create_model('swin_*', features_only=True, out_indices=(0,1,2,3)): FeatureListNet over
     patch_embed, layers_0..3 (flatten_sequential), NHWC feature maps."""
 
-    def __init__(self, name: str, in_chans: int, img_size: int):
+    def __init__(self, name: str, in_chans: int, img_size: int, drop_path_rate: float = 0.1):
         super().__init__()
         dim, depths, heads, ws, patch = parse_swin_name(name)
         self.patch_embed = PatchEmbed(in_chans, dim, patch)
         res = img_size // patch
         dims = [dim * 2 ** i for i in range(4)]
         self.channels = dims
+        total = sum(depths)
+        dpr = [drop_path_rate * i / max(total - 1, 1) for i in range(total)]  # torch.linspace(0, rate, total)
         for i in range(4):
             if i > 0:
                 res = (res + 1) // 2
-            stage = SwinStage(dims[i - 1] if i else dim, dims[i], (res, res), depths[i], heads[i], ws, i > 0)
+            stage = SwinStage(dims[i - 1] if i else dim, dims[i], (res, res), depths[i], heads[i], ws, i > 0,
+                              dpr[sum(depths[:i]):sum(depths[:i + 1])])
             setattr(self, f"layers_{i}", stage)
         self.apply(self._init)
 
@@ -234,9 +256,9 @@ class TimmUniversalEncoder(nn.Module):
     """smp 0.4.0 encoders/timm_universal.py for a transformer-style (stride-4 first) channel-last backbone:
     [x, 0-channel dummy at stride 2, f4, f8, f16, f32] in NCHW"""
 
-    def __init__(self, name: str, in_channels: int, img_size: int):
+    def __init__(self, name: str, in_channels: int, img_size: int, drop_path_rate: float = 0.1):
         super().__init__()
-        self.model = SwinFeatures(name, in_channels, img_size)
+        self.model = SwinFeatures(name, in_channels, img_size, drop_path_rate)
         self.out_channels = [in_channels, 0] + list(self.model.channels)
 
     def forward(self, x):
@@ -310,9 +332,10 @@ class SegmentationHead(nn.Sequential):
 class SwinUPerNet(nn.Module):
     """What smp.create_model(arch='upernet', encoder_name='tu-swin_...', classes, in_channels, img_size) returns."""
 
-    def __init__(self, encoder_name: str, in_channels: int = 3, classes: int = 1, img_size: int = 512):
+    def __init__(self, encoder_name: str, in_channels: int = 3, classes: int = 1, img_size: int = 512,
+                 drop_path_rate: float = 0.1):
         super().__init__()
-        self.encoder = TimmUniversalEncoder(encoder_name, in_channels, img_size)
+        self.encoder = TimmUniversalEncoder(encoder_name, in_channels, img_size, drop_path_rate)
         self.decoder = UPerNetDecoder(self.encoder.out_channels)
         self.segmentation_head = SegmentationHead(64, classes)
 

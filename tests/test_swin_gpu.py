@@ -248,7 +248,7 @@ def test_swin_upernet_matches_oracle(name, ch, size, precision):
         assert (logits.argmax(1) == ref.argmax(1)).float().mean().item() >= 0.97
 
 
-def test_swin_state_dict_accepts_timm_spelling_and_training_refuses():
+def test_swin_state_dict_accepts_timm_spelling_and_fp32_training_refuses():
     from flairhip.swin import SwinUPerNet
     m = SwinUPerNet("swin_tiny_patch4_window7_224", 3, 5, 64)
     sd = {k.replace("layers_", "layers."): v for k, v in m.state_dict().items()}
@@ -258,8 +258,8 @@ def test_swin_state_dict_accepts_timm_spelling_and_training_refuses():
     for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
     m2 = m2.to(DEV).train()
-    with pytest.raises(NotImplementedError):
-        m2.encoder(torch.zeros(1, 64, 64, 16, device=DEV, dtype=torch.bfloat16))
+    with pytest.raises(NotImplementedError):  # the fp32 parity mode has no training path (bf16 attention backward)
+        m2.encoder(torch.zeros(1, 64, 64, 16, device=DEV, dtype=torch.float32))
 
 
 # ---------------------------------------------------------------------------------------------------- FLAIR_HUB_Model glue
@@ -358,3 +358,218 @@ def test_zonal_run_with_swin_upernet_matches_the_oracle_loop(tmp_path, output_ty
     else:
         assert np.abs(got.astype(int) - canvas.astype(int)).max() <= 1
     assert got.any()
+
+
+# ---------------------------------------------------------------------------------------------------- backward kernels
+
+def test_linear_training_epilogues():
+    """fc1 keeps its pre-activation, fc2's input gradient goes through gelu', DropPath scales rows per sample"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(21)
+    M, K, N = 384, 128, 256
+    x, w, b = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) / math.sqrt(K)), torch.randn(N, generator=g)
+    u_ref = _bf(F.linear(x.float(), w.float(), b))
+    aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    h = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=ops.ACT_GELU, aux=aux)
+    assert (aux.float().cpu() - u_ref.float()).abs().max().item() <= 3e-2
+    assert (h.float().cpu() - F.gelu(aux.float().cpu())).abs().max().item() <= 2e-2
+    # dgelu: out = (dy W2) * gelu'(u)
+    dy = _bf(torch.randn(M, K, generator=g))
+    w2t = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))  # [N_out = hidden, K = features of dy]
+    u = aux.float().cpu().requires_grad_(True)
+    F.gelu(u).backward(F.linear(dy.float(), w2t.float()))
+    got = ops.linear(dy.to(DEV), w2t.to(DEV), None, act=ops.ACT_DGELU, aux=aux)
+    assert (got.float().cpu() - u.grad).abs().max().item() <= 3e-2 * max(1.0, u.grad.abs().max().item())
+    # row scale + residual
+    rs = torch.tensor([0.0, 1.25, 1.0], device=DEV)
+    r = _bf(torch.randn(M, N, generator=g))
+    y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), residual=r.to(DEV), row_scale=rs, rows_per_scale=128)
+    ref = _bf(F.linear(x.float(), w.float(), b)).float() * rs.cpu().repeat_interleave(128)[:, None] + r.float()
+    assert (y.float().cpu() - ref).abs().max().item() <= 3e-2 * max(1.0, ref.abs().max().item())
+    assert torch.equal(y[:128].cpu(), r[:128])  # a dropped sample keeps its residual bit for bit
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [96, 256, 1024])
+def test_layer_norm_backward(dtype, C):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(C + 1)
+    x = (torch.randn(3, 7, 9, C, generator=g) * 1.5 + 0.3).to(dtype)
+    dy = torch.randn(3, 7, 9, C, generator=g).to(dtype)
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    xr, wr, br = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.layer_norm(xr, (C,), wr, br, 1e-5).backward(dy.float())
+    stats = torch.empty(3 * 7 * 9, 2, device=DEV)
+    ops.layer_norm(x.to(DEV), w.to(DEV), b.to(DEV), stats=stats)
+    dx, dg, db = ops.layer_norm_bwd(x.to(DEV), dy.to(DEV), w.to(DEV), stats)
+    tol = 5e-5 if dtype == torch.float32 else 5e-2
+    assert (dx.float().cpu() - xr.grad).abs().max().item() <= tol * max(1.0, xr.grad.abs().max().item())
+    assert (dg.cpu() - wr.grad).abs().max().item() <= (1e-3 if dtype == torch.float32 else 0.3)
+    assert (db.cpu() - br.grad).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_patch_merge_norm_backward(dtype):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(8)
+    C = 96
+    x = torch.randn(2, 8, 12, C, generator=g).to(dtype)
+    dy = torch.randn(2, 4, 6, 4 * C, generator=g).to(dtype)
+    w, b = torch.rand(4 * C, generator=g) + 0.5, torch.randn(4 * C, generator=g)
+    xr, wr, br = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    merged = xr.reshape(2, 4, 2, 6, 2, C).permute(0, 1, 3, 4, 2, 5).flatten(3)
+    F.layer_norm(merged, (4 * C,), wr, br, 1e-5).backward(dy.float())
+    stats = torch.empty(2 * 4 * 6, 2, device=DEV)
+    ops.patch_merge_norm(x.to(DEV), w.to(DEV), b.to(DEV), stats=stats)
+    dx, dg, db = ops.patch_merge_norm_bwd(x.to(DEV), dy.to(DEV), w.to(DEV), stats)
+    tol = 5e-5 if dtype == torch.float32 else 5e-2
+    assert (dx.float().cpu() - xr.grad).abs().max().item() <= tol * max(1.0, xr.grad.abs().max().item())
+    assert (dg.cpu() - wr.grad).abs().max().item() <= (1e-3 if dtype == torch.float32 else 0.2)
+    assert (db.cpu() - br.grad).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("H,W,heads,ws,shift", [
+    (14, 14, 3, 7, 0), (16, 16, 3, 7, 3), (16, 20, 4, 7, 0), (4, 4, 3, 4, 0), (24, 24, 4, 12, 6), (32, 32, 4, 12, 6),
+    (32, 32, 2, 12, 0), (12, 12, 8, 12, 0),
+])
+def test_window_attention_backward(H, W, heads, ws, shift):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(H * 17 + ws + shift)
+    C = heads * 32
+    qkv = _bf(torch.randn(2, H, W, 3 * C, generator=g))
+    dout = _bf(torch.randn(2, H, W, C, generator=g))
+    bias = _bf(torch.randn(3 * C, generator=g)).float()
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g) * 0.5
+    qr, br, tr = qkv.float().requires_grad_(True), bias.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    _attention_reference(qr, br, tr, heads, ws, shift).backward(dout.float())
+    dq, dt, db = ops.window_attention_bwd(qkv.to(DEV), dout.to(DEV), bias.to(DEV), table.to(DEV), heads, ws, shift,
+                                          32 ** -0.5)
+    rel = lambda a, b: ((a - b).norm() / (b.norm() + 1e-12)).item()
+    assert rel(dq.float().cpu(), qr.grad) <= 2e-2
+    assert (dq.float().cpu() - qr.grad).abs().max().item() <= 5e-2 * max(1.0, qr.grad.abs().max().item())
+    assert rel(dt.cpu(), tr.grad) <= 2e-2
+    if br.grad.abs().max() > 0:  # the map is not a multiple of the window: padding tokens carry the bias
+        assert rel(db.cpu(), br.grad) <= 2e-2
+    else:
+        assert db.abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("align", [False, True])
+@pytest.mark.parametrize("hw_in,hw_out", [((4, 4), (16, 16)), ((6, 6), (16, 16)), ((16, 16), (16, 16)),
+                                           ((32, 32), (16, 16)), ((1, 1), (16, 16)), ((8, 12), (32, 48)), ((32, 32), (128, 128))])
+def test_bilinear_slice_backward(dtype, align, hw_in, hw_out):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(13)
+    C = 16
+    dyw = torch.randn(2, *hw_out, 48, generator=g).to(dtype)
+    xr = torch.zeros(2, C, *hw_in, requires_grad=True)
+    F.interpolate(xr, size=hw_out, mode="bilinear", align_corners=align).backward(
+        dyw[..., 16:32].float().permute(0, 3, 1, 2))
+    dx = ops.bilinear_slice_bwd(dyw.to(DEV), hw_in, C, offset=16, align_corners=align).float().cpu()
+    ref = xr.grad.permute(0, 2, 3, 1)
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert (dx - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_adaptive_avg_pool_backward(dtype):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(14)
+    for s in (1, 2, 3, 6):
+        dy = torch.randn(2, s, s, 32, generator=g).to(dtype)
+        xr = torch.zeros(2, 32, 16, 16, requires_grad=True)
+        F.adaptive_avg_pool2d(xr, s).backward(dy.float().permute(0, 3, 1, 2))
+        dx = ops.adaptive_avg_pool_bwd(dy.to(DEV), (16, 16)).float().cpu()
+        ref = xr.grad.permute(0, 2, 3, 1)
+        assert (dx - ref).abs().max().item() <= (1e-5 if dtype == torch.float32 else 2e-2), s
+
+
+# ---------------------------------------------------------------------------------------------------- training
+
+def _grad_pair(name, ch, size, B=2, seed=7):
+    from flairhip import ops
+    from flairhip.swin import SwinUPerNet
+    from oracle.swin_upernet import SwinUPerNet as OracleNet
+    torch.manual_seed(1)
+    oracle = OracleNet(name, ch, 19, size, drop_path_rate=0.0).train()
+    _randomise(oracle, seed)
+    model = SwinUPerNet(name, ch, 19, size, drop_path_rate=0.0)
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    model = model.to(DEV).train()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, ch, size, size, generator=g)
+    tgt = torch.randint(0, 19, (B, size, size), generator=g)
+    return oracle, model, x, tgt
+
+
+def test_swin_upernet_training_step_gradients_match_oracle_autograd():
+    """bf16 training step (drop_path 0) against torch autograd through the fp32 CPU oracle: loss, every parameter
+    gradient by cosine similarity / relative norm -- the bound is bf16 rounding, as for the U-Net's bf16 gradients"""
+    from flairhip import nn as hnn
+    from flairhip import ops
+    name, ch, size = "swin_tiny_patch4_window7_224", 5, 128
+    # batch 6: the PSP branch with pool size 1 runs a training-mode BatchNorm over B samples per channel; with 2 samples
+    # its backward amplifies bf16 rounding of the last feature map to a 20 % error in every encoder gradient
+    oracle, model, x, tgt = _grad_pair(name, ch, size, B=6)
+    ref_logits = oracle(x)
+    ref_loss = F.cross_entropy(ref_logits, tgt)
+    ref_loss.backward()
+    xn = ops.nchw_to_nhwc(x.to(DEV), torch.bfloat16, ops.pad_channels(ch))
+    y = model(xn)
+    logits = hnn.logits_view(y, 19)
+    crit = hnn.HipCrossEntropyLoss(num_classes=19).to(DEV)
+    loss = crit(logits, tgt.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref_loss.item()) <= 2e-2 * abs(ref_loss.item())
+    ref_grads = dict(oracle.named_parameters())
+    bad, cos_all = [], []
+    for k, p in model.named_parameters():
+        if "fpn_stages.4" in k:  # the FPNBlock of the input image is never called (smp drops features[0])
+            assert p.grad is None and ref_grads[k].grad is None
+            continue
+        assert p.grad is not None, k
+        a, b = p.grad.float().cpu().flatten(), ref_grads[k].grad.flatten()
+        if k.endswith("layers_3.blocks.1.mlp.fc2.bias"):
+            # a per-channel constant added to the last feature map is removed by the training-mode BatchNorms that follow
+            # every consumer (PSP convolutions): the exact gradient is 0, the oracle's value is f32 round-off
+            assert b.abs().max().item() < 1e-6 and a.abs().max().item() < 5e-3
+            continue
+        cos = F.cosine_similarity(a, b, dim=0).item()
+        cos_all.append(cos)
+        ratio = (a.norm() / (b.norm() + 1e-20)).item()
+        if cos < 0.95 or not (0.8 < ratio < 1.25):
+            bad.append((k, round(cos, 4), round(ratio, 3)))
+    assert not bad, bad[:12]
+    assert sum(cos_all) / len(cos_all) > 0.99
+
+
+def test_swin_training_reduces_the_loss_and_drop_path_is_stochastic():
+    from flairhip import nn as hnn
+    from flairhip import ops
+    from flairhip.swin import SwinUPerNet
+    torch.manual_seed(3)
+    model = SwinUPerNet("swin_tiny_patch4_window7_224", 3, 19, 64, drop_path_rate=0.2).to(DEV).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(4, 3, 64, 64, generator=g).to(DEV)
+    tgt = torch.randint(0, 19, (4, 64, 64), generator=g).to(DEV)
+    crit = hnn.HipCrossEntropyLoss(num_classes=19).to(DEV)
+    xn = ops.nchw_to_nhwc(x, torch.bfloat16, ops.pad_channels(3))
+    losses = []
+    for _ in range(30):
+        opt.zero_grad(set_to_none=True)
+        loss = crit(hnn.logits_view(model(xn), 19), tgt)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert min(losses[-5:]) < 0.95 * losses[0], losses  # random per-pixel labels: memorising 4 tiles is slow
+    with torch.no_grad():  # train mode without autograd: the evaluation kernels, no DropPath draw
+        a = model(xn)
+        b = model(xn)
+    assert torch.equal(a, b)
+    y1, y2 = model(xn), model(xn)  # two training forwards draw different DropPath masks
+    assert not torch.equal(y1, y2)
+    with pytest.raises(NotImplementedError):
+        model(ops.nchw_to_nhwc(x, torch.float32, ops.pad_channels(3)))
