@@ -1049,6 +1049,77 @@ extern "C" int ffa_adaptive_avg_pool_bwd(int dtype, const void* dy, void* dx, in
   return ffa_check_launch("adaptive_avg_pool_bwd");
 }
 
+// ---- out[c] = sum_m x[m][c] (f32): nn.Linear's bias gradient for any width (ffa_channel_sums stops at 2048 channels).
+// Chunk partials in the workspace, summed in a fixed order: deterministic.
+template <typename T>
+__global__ void __launch_bounds__(256) column_sums_kernel(const T* __restrict__ x, float* __restrict__ partial,
+                                                          long long rows, int C, long long rows_per_chunk) {
+  __shared__ float red[8][32][8];
+  const int CG = C / 8;
+  const int gl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int g = blockIdx.x * 32 + gl;
+  const long long r0 = blockIdx.y * rows_per_chunk;
+  long long r1 = r0 + rows_per_chunk;
+  if (r1 > rows) r1 = rows;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (g < CG) {
+    for (long long row = r0 + rl; row < r1; row += 8) {
+      float v[8];
+      ffa_load8<T>(x + row * (long long)C + g * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][gl][e] = acc[e];
+  __syncthreads();
+  if (rl == 0 && g < CG) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v += red[r][gl][e];
+      partial[(long long)blockIdx.y * C + g * 8 + e] = v;
+    }
+  }
+}
+
+__global__ void column_sums_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int C, int chunks,
+                                          int pitch) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int k = 0; k < chunks; ++k) a += partial[(long long)k * pitch + c];
+  out[c] = a;
+}
+
+extern "C" long long ffa_column_sums_workspace_bytes(long long rows, int C) {
+  return (long long)ln_bwd_chunks(rows) * C * (long long)sizeof(float);
+}
+
+extern "C" int ffa_column_sums(int dtype, const void* x, float* out, long long rows, int C, void* workspace,
+                               long long workspace_bytes, hipStream_t stream) {
+  FFA_REQUIRE(x && out && rows > 0 && C > 0 && C % 8 == 0, "column_sums: bad arguments");
+  if (!workspace || workspace_bytes < ffa_column_sums_workspace_bytes(rows, C)) {
+    ffa_set_error("column_sums: workspace of %lld bytes needed", ffa_column_sums_workspace_bytes(rows, C));
+    return FFA_ERR_WORKSPACE;
+  }
+  const int chunks = ln_bwd_chunks(rows);
+  const long long rpc = (rows + chunks - 1) / chunks;
+  const dim3 grid((unsigned)((C / 8 + 31) / 32), (unsigned)chunks);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(column_sums_kernel<ffa_bf16>, grid, dim3(256), 0, stream, (const ffa_bf16*)x, (float*)workspace,
+                       rows, C, rpc);
+  else
+    hipLaunchKernelGGL(column_sums_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (float*)workspace, rows, C,
+                       rpc);
+  hipLaunchKernelGGL(column_sums_reduce_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream,
+                     (const float*)workspace, out, C, chunks, C);
+  return ffa_check_launch("column_sums");
+}
+
 // ------------------------------------------------------------------------------------------------
 // Window attention backward (bf16, MFMA 16x16x32).  One block per (window, head); q, k, v and dO of the window's
 // tokens are staged once in LDS (row-major [NP][32] at a 96-byte pitch: row fragments by ds_read_b128, transposed
@@ -1064,12 +1135,12 @@ extern "C" int ffa_adaptive_avg_pool_bwd(int dtype, const void* dy, void* dx, in
 template <int NTP, int NW>
 __global__ void __launch_bounds__(64 * NW) window_attention_bwd_kernel(WinAttnArgs a, const ffa_bf16* __restrict__ dout,
                                                                        ffa_bf16* __restrict__ dqkv,
-                                                                       float* __restrict__ dtable,
-                                                                       float* __restrict__ dbias_pad) {
+                                                                       float* __restrict__ table_partial, int table_pitch,
+                                                                       float* __restrict__ pad_partial) {
   constexpr int NP = NTP * 16;
   constexpr int RP = 96;  // row pitch in bytes
   constexpr float LOG2E = 1.4426950408889634f;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * NP * RP + NP * 16 + 2 * 529 * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * NP * RP + NP * 16 + 2 * 529 * 4 + 96 * 4];
   unsigned char* sq = smem;
   unsigned char* sk = sq + NP * RP;
   unsigned char* sv = sk + NP * RP;
@@ -1080,6 +1151,7 @@ __global__ void __launch_bounds__(64 * NW) window_attention_bwd_kernel(WinAttnAr
   float* sdelta = sli + NP;                                   // [NP]
   float* stab = sdelta + NP;                                  // [529]
   float* sdtab = stab + 529;                                  // [529]
+  float* spad = sdtab + 529;                                  // [3][32] gradients of the window's padding tokens
   const int N = a.ws * a.ws;
   const int head = blockIdx.y;
   int w = blockIdx.x;
@@ -1094,6 +1166,7 @@ __global__ void __launch_bounds__(64 * NW) window_attention_bwd_kernel(WinAttnAr
     stab[i] = a.table[i * a.heads + head] * LOG2E;
     sdtab[i] = 0.f;
   }
+  if (threadIdx.x < 96) spad[threadIdx.x] = 0.f;
   const float scale2 = a.scale * LOG2E;
   const bool masked = a.shift > 0 && (wy == a.nwy - 1 || wx == a.nwx - 1);
   for (int i = threadIdx.x; i < NP * 4; i += 64 * NW) {
@@ -1160,11 +1233,11 @@ __global__ void __launch_bounds__(64 * NW) window_attention_bwd_kernel(WinAttnAr
       *reinterpret_cast<uint2*>(dst) = l2;
       *reinterpret_cast<uint2*>(dst + 16) = h2;
     } else if (off == -1) {  // padding token inside the window: its q / k / v are the bias
-      float* dst = dbias_pad + which * a.C + head * 32 + g * 4;
+      float* dst = spad + which * 32 + g * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        atomicAdd(dst + e, lo[e] * mul);
-        atomicAdd(dst + 16 + e, hi[e] * mul);
+        unsafeAtomicAdd(dst + e, lo[e] * mul);       // ds_add_f32
+        unsafeAtomicAdd(dst + 16 + e, hi[e] * mul);
       }
     }
   };
@@ -1241,7 +1314,7 @@ __global__ void __launch_bounds__(64 * NW) window_attention_bwd_kernel(WinAttnAr
       for (int i = 0; i < 4; ++i) {
         const float ds = s[t][i] * (dp[t][i] - delta);
         s[t][i] = ds;
-        if (ds != 0.f) atomicAdd(&sdtab[qlin - (kk[i] & 0xffff)], ds);
+        if (ds != 0.f) unsafeAtomicAdd(&sdtab[qlin - (kk[i] & 0xffff)], ds);  // ds_add_f32
       }
     }
     ffa_f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
@@ -1314,20 +1387,56 @@ __global__ void __launch_bounds__(64 * NW) window_attention_bwd_kernel(WinAttnAr
     store_grad(ki, 2, v0, v1, 1.0f);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < TS; i += 64 * NW) {
-    const float v = sdtab[i];
-    if (v != 0.f) atomicAdd(&dtable[i * a.heads + head], v);
+  // this block's share of the bias-table gradient and of the padding tokens' gradient: one row per window, the
+  // columns of this head; the rows are summed by column_sums_kernel afterwards (no global atomics, fixed order)
+  float* trow = table_partial + (long long)blockIdx.x * table_pitch;
+  for (int i = threadIdx.x; i < TS; i += 64 * NW) trow[i * a.heads + head] = sdtab[i];
+  if (head == 0)
+    for (int i = TS * a.heads + threadIdx.x; i < table_pitch; i += 64 * NW) trow[i] = 0.f;
+  if (pad_partial) {
+    const bool last_row = wy == a.nwy - 1, last_col = wx == a.nwx - 1;
+    if (last_row || last_col) {  // the only windows that can hold padding tokens
+      const int slot = b * (a.nwx + a.nwy - 1) + (last_row ? wx : a.nwx + wy);
+      if (threadIdx.x < 96)
+        pad_partial[(long long)slot * (3 * a.C) + (threadIdx.x >> 5) * a.C + head * 32 + (threadIdx.x & 31)] =
+            spad[threadIdx.x];
+    }
   }
+}
+
+static inline long long attn_bwd_table_pitch(int heads, int ws) {
+  const long long n = (long long)(2 * ws - 1) * (2 * ws - 1) * heads;
+  return (n + 7) / 8 * 8;
+}
+
+extern "C" long long ffa_window_attention_bwd_workspace_bytes(int B, int H, int W, int C, int heads, int ws) {
+  const int nwy = (H + ws - 1) / ws, nwx = (W + ws - 1) / ws;
+  const long long nwin = (long long)B * nwy * nwx;
+  const long long pitch = attn_bwd_table_pitch(heads, ws);
+  const long long pad_rows = (H % ws || W % ws) ? (long long)B * (nwx + nwy - 1) : 0;
+  const long long red = ln_bwd_chunks(nwin) * (pitch > 3LL * C ? pitch : 3LL * C);
+  return (nwin * pitch + pad_rows * 3 * C + red) * (long long)sizeof(float);
+}
+
+__global__ void zero_f32_kernel(float* p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
 }
 
 extern "C" int ffa_window_attention_bwd(int dtype, const void* qkv, const void* dout, void* dqkv, const float* qkv_bias,
                                         const float* table, float* dtable, float* dbias_pad, int B, int H, int W, int C,
-                                        int heads, int ws, int shift, float scale, hipStream_t stream) {
+                                        int heads, int ws, int shift, float scale, void* workspace,
+                                        long long workspace_bytes, hipStream_t stream) {
   FFA_REQUIRE(dtype == FFA_BF16, "window_attention_bwd: bf16 only (no f32 training mode for the transformer layers)");
   FFA_REQUIRE(qkv && dout && dqkv && qkv_bias && table && dtable && dbias_pad && B > 0 && H > 0 && W > 0 && heads > 0,
               "window_attention_bwd: bad arguments");
   FFA_REQUIRE(C == heads * 32, "window_attention_bwd: head dimension %d (only 32 is built)", heads ? C / heads : 0);
   FFA_REQUIRE(ws >= 1 && ws <= 12 && shift >= 0 && shift < ws, "window_attention_bwd: window %d / shift %d", ws, shift);
+  if (!workspace || workspace_bytes < ffa_window_attention_bwd_workspace_bytes(B, H, W, C, heads, ws)) {
+    ffa_set_error("window_attention_bwd: workspace of %lld bytes needed",
+                  ffa_window_attention_bwd_workspace_bytes(B, H, W, C, heads, ws));
+    return FFA_ERR_WORKSPACE;
+  }
   WinAttnArgs a;
   a.qkv = qkv;
   a.out = nullptr;
@@ -1339,13 +1448,38 @@ extern "C" int ffa_window_attention_bwd(int dtype, const void* qkv, const void* 
   a.scale = scale;
   const long long nwin = (long long)B * a.nwy * a.nwx;
   FFA_REQUIRE(nwin < (1LL << 31) && heads < 65536, "window_attention_bwd: grid too large");
+  const int pitch = (int)attn_bwd_table_pitch(heads, ws);
+  const long long pad_rows = (H % ws || W % ws) ? (long long)B * (a.nwx + a.nwy - 1) : 0;
+  float* table_partial = (float*)workspace;
+  float* pad_partial = pad_rows ? table_partial + nwin * pitch : nullptr;
+  float* red = table_partial + nwin * pitch + pad_rows * 3 * C;
   const dim3 grid((unsigned)nwin, (unsigned)heads);
   if (ws * ws <= 64)
     hipLaunchKernelGGL((window_attention_bwd_kernel<4, 4>), grid, dim3(256), 0, stream, a, (const ffa_bf16*)dout,
-                       (ffa_bf16*)dqkv, dtable, dbias_pad);
+                       (ffa_bf16*)dqkv, table_partial, pitch, pad_partial);
   else
     hipLaunchKernelGGL((window_attention_bwd_kernel<10, 3>), grid, dim3(192), 0, stream, a, (const ffa_bf16*)dout,
-                       (ffa_bf16*)dqkv, dtable, dbias_pad);
+                       (ffa_bf16*)dqkv, table_partial, pitch, pad_partial);
+  // fixed-order sums over the windows: d table [TS][heads] and the padding tokens' share of d qkv_bias [3C]
+  {
+    const int chunks = ln_bwd_chunks(nwin);
+    const long long rpc = (nwin + chunks - 1) / chunks;
+    hipLaunchKernelGGL(column_sums_kernel<float>, dim3((unsigned)((pitch / 8 + 31) / 32), (unsigned)chunks), dim3(256), 0,
+                       stream, (const float*)table_partial, red, nwin, pitch, rpc);
+    const int TSH = (2 * ws - 1) * (2 * ws - 1) * heads;
+    hipLaunchKernelGGL(column_sums_reduce_kernel, dim3((unsigned)((TSH + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)red, dtable, TSH, chunks, pitch);
+  }
+  if (pad_rows) {
+    const int chunks = ln_bwd_chunks(pad_rows);
+    const long long rpc = (pad_rows + chunks - 1) / chunks;
+    hipLaunchKernelGGL(column_sums_kernel<float>, dim3((unsigned)((3 * C / 8 + 31) / 32), (unsigned)chunks), dim3(256), 0,
+                       stream, (const float*)pad_partial, red, pad_rows, 3 * C, rpc);
+    hipLaunchKernelGGL(column_sums_reduce_kernel, dim3((unsigned)((3 * C + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)red, dbias_pad, 3 * C, chunks, 3 * C);
+  } else {
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((3 * C + 255) / 256)), dim3(256), 0, stream, dbias_pad, 3 * C);
+  }
   return ffa_check_launch("window_attention_bwd");
 }
 
@@ -1379,74 +1513,4 @@ extern "C" int ffa_scale_rows(int dtype, const void* x, void* y, const float* ro
     hipLaunchKernelGGL(scale_rows_kernel<float>, dim3(tf_grid(items)), dim3(FFA_TF_THREADS), 0, stream, (const float*)x,
                        (float*)y, row_scale, rows, C, rows_per_scale);
   return ffa_check_launch("scale_rows");
-}
-
-// ---- out[c] = sum_m x[m][c] (f32): nn.Linear's bias gradient for any width (ffa_channel_sums stops at 2048 channels).
-// Chunk partials in the workspace, summed in a fixed order: deterministic.
-template <typename T>
-__global__ void __launch_bounds__(256) column_sums_kernel(const T* __restrict__ x, float* __restrict__ partial,
-                                                          long long rows, int C, long long rows_per_chunk) {
-  __shared__ float red[8][32][8];
-  const int CG = C / 8;
-  const int gl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int g = blockIdx.x * 32 + gl;
-  const long long r0 = blockIdx.y * rows_per_chunk;
-  long long r1 = r0 + rows_per_chunk;
-  if (r1 > rows) r1 = rows;
-  float acc[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  if (g < CG) {
-    for (long long row = r0 + rl; row < r1; row += 8) {
-      float v[8];
-      ffa_load8<T>(x + row * (long long)C + g * 8, v);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += v[e];
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) red[rl][gl][e] = acc[e];
-  __syncthreads();
-  if (rl == 0 && g < CG) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = 0.f;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v += red[r][gl][e];
-      partial[(long long)blockIdx.y * C + g * 8 + e] = v;
-    }
-  }
-}
-
-__global__ void column_sums_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int C, int chunks) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float a = 0.f;
-  for (int k = 0; k < chunks; ++k) a += partial[(long long)k * C + c];
-  out[c] = a;
-}
-
-extern "C" long long ffa_column_sums_workspace_bytes(long long rows, int C) {
-  return (long long)ln_bwd_chunks(rows) * C * (long long)sizeof(float);
-}
-
-extern "C" int ffa_column_sums(int dtype, const void* x, float* out, long long rows, int C, void* workspace,
-                               long long workspace_bytes, hipStream_t stream) {
-  FFA_REQUIRE(x && out && rows > 0 && C > 0 && C % 8 == 0, "column_sums: bad arguments");
-  if (!workspace || workspace_bytes < ffa_column_sums_workspace_bytes(rows, C)) {
-    ffa_set_error("column_sums: workspace of %lld bytes needed", ffa_column_sums_workspace_bytes(rows, C));
-    return FFA_ERR_WORKSPACE;
-  }
-  const int chunks = ln_bwd_chunks(rows);
-  const long long rpc = (rows + chunks - 1) / chunks;
-  const dim3 grid((unsigned)((C / 8 + 31) / 32), (unsigned)chunks);
-  if (dtype == FFA_BF16)
-    hipLaunchKernelGGL(column_sums_kernel<ffa_bf16>, grid, dim3(256), 0, stream, (const ffa_bf16*)x, (float*)workspace,
-                       rows, C, rpc);
-  else
-    hipLaunchKernelGGL(column_sums_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (float*)workspace, rows, C,
-                       rpc);
-  hipLaunchKernelGGL(column_sums_reduce_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream,
-                     (const float*)workspace, out, C, chunks);
-  return ffa_check_launch("column_sums");
 }

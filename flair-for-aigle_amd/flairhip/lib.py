@@ -87,7 +87,8 @@ SIGNATURES = {
     "ffa_column_sums_workspace_bytes": (_ll, [_ll, _i]),
     "ffa_column_sums": (_i, [_i, _p, _p, _ll, _i, _p, _ll, _p]),
     "ffa_patch_merge_norm_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _ll, _p]),
-    "ffa_window_attention_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "ffa_window_attention_bwd_workspace_bytes": (_ll, [_i] * 6),
+    "ffa_window_attention_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _ll, _p]),
     "ffa_bilinear_slice_bwd": (_i, [_i, _p, _p] + [_i] * 9 + [_p]),
     "ffa_adaptive_avg_pool_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ffa_window_attention": (_i, [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),

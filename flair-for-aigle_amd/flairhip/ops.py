@@ -1071,12 +1071,14 @@ def window_attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, qkv_bias: torch.
     C = C3 // 3
     if dout.shape != (B, H, W, C) or dout.dtype != qkv.dtype:
         raise ValueError("window_attention_bwd: dout must be [B,H,W,C] in the dtype of qkv")
+    lib = _l.load()
     dqkv = torch.empty_like(qkv)
-    dtable = torch.zeros_like(table)
-    dbias = torch.zeros(C3, dtype=torch.float32, device=qkv.device)
-    _l.check(_l.load().ffa_window_attention_bwd(_dt(qkv), qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(),
-                                                qkv_bias.data_ptr(), table.data_ptr(), dtable.data_ptr(),
-                                                dbias.data_ptr(), B, H, W, C, heads, ws, shift, scale, _stream()),
+    dtable = torch.empty_like(table)
+    dbias = torch.empty(C3, dtype=torch.float32, device=qkv.device)
+    wsp = workspace(lib.ffa_window_attention_bwd_workspace_bytes(B, H, W, C, heads, ws), qkv.device, "attn_bwd")
+    _l.check(lib.ffa_window_attention_bwd(_dt(qkv), qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(),
+                                          qkv_bias.data_ptr(), table.data_ptr(), dtable.data_ptr(), dbias.data_ptr(), B,
+                                          H, W, C, heads, ws, shift, scale, wsp.data_ptr(), wsp.numel(), _stream()),
              "window_attention_bwd")
     return dqkv, dtable, dbias
 

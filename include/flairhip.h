@@ -210,11 +210,13 @@ int ffa_patch_merge_norm_bwd(int dtype, const void* x, const void* dy, const flo
 int ffa_window_attention(int dtype, const void* qkv, void* out, const float* qkv_bias, const float* table, int B, int H,
                          int W, int C, int heads, int ws, int shift, float scale, ffa_stream_t stream);
 /* backward of ffa_window_attention (bf16): dqkv [B][H][W][3C] from qkv and dout [B][H][W][C]; dtable [(2 ws - 1)^2][heads]
- * and dbias_pad [3C] (gradient reaching the qkv bias through the padding tokens) are ACCUMULATED with f32 atomics and
- * must be zeroed by the caller */
+ * and dbias_pad [3C] (gradient reaching the qkv bias through the padding tokens) are written (per-window partial rows in
+ * the workspace, summed in a fixed order; only LDS atomics inside a block) */
+long long ffa_window_attention_bwd_workspace_bytes(int B, int H, int W, int C, int heads, int ws);
 int ffa_window_attention_bwd(int dtype, const void* qkv, const void* dout, void* dqkv, const float* qkv_bias,
                              const float* table, float* dtable, float* dbias_pad, int B, int H, int W, int C, int heads,
-                             int ws, int shift, float scale, ffa_stream_t stream);
+                             int ws, int shift, float scale, void* workspace, long long workspace_bytes,
+                             ffa_stream_t stream);
 /* nn.GELU() (erf form), elementwise; n a multiple of 8 */
 int ffa_gelu(int dtype, const void* x, void* y, long long n, ffa_stream_t stream);
 /* nn.AdaptiveAvgPool2d(S) of smp's PSPModule: x [B][H][W][C] -> y [B][S][S][C] */
