@@ -331,17 +331,27 @@ __global__ void __launch_bounds__(256) layer_norm_bwd_params_kernel(const T* __r
   }
 }
 
-__global__ void layer_norm_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                             float* __restrict__ dbeta, int C, int chunks) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ void __launch_bounds__(256) layer_norm_bwd_reduce_kernel(const float* __restrict__ partial,
+                                                                    float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, int C, int chunks) {
+  // 32 lanes per channel over the chunks, combined by xor-shuffles (fixed order)
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int l = threadIdx.x & 31;
   float a = 0.f, b = 0.f;
-  for (int k = 0; k < chunks; ++k) {
-    a += partial[((long long)k * 2) * C + c];
-    b += partial[((long long)k * 2 + 1) * C + c];
+  if (c < C)
+    for (int k = l; k < chunks; k += 32) {
+      a += partial[((long long)k * 2) * C + c];
+      b += partial[((long long)k * 2 + 1) * C + c];
+    }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
   }
-  dgamma[c] = a;
-  dbeta[c] = b;
+  if (c < C && l == 0) {
+    dgamma[c] = a;
+    dbeta[c] = b;
+  }
 }
 
 static inline int ln_bwd_chunks(long long rows) {
@@ -382,7 +392,7 @@ static int layer_norm_bwd_launch(const void* x, const void* dy, const float* gam
   const long long rpc = (rows + chunks - 1) / chunks;
   hipLaunchKernelGGL((layer_norm_bwd_params_kernel<T, MERGE>), dim3((unsigned)((CG + 31) / 32), (unsigned)chunks), dim3(256),
                      0, stream, (const T*)x, (const T*)dy, stats, (float*)workspace, rows, C, Ho, Wo, rpc);
-  hipLaunchKernelGGL(layer_norm_bwd_reduce_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(layer_norm_bwd_reduce_kernel, dim3((unsigned)((C + 7) / 8)), dim3(256), 0, stream,
                      (const float*)workspace, dgamma, dbeta, C, chunks);
   return ffa_check_launch(MERGE ? "patch_merge_norm_bwd" : "layer_norm_bwd");
 }
@@ -1086,13 +1096,18 @@ __global__ void __launch_bounds__(256) column_sums_kernel(const T* __restrict__ 
   }
 }
 
-__global__ void column_sums_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int C, int chunks,
-                                          int pitch) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// out[c] = sum_k partial[k][c]: 32 lanes per column take the chunks k = lane, lane + 32, ... and are combined by
+// xor-shuffles -- a fixed summation order, 16 dependent loads instead of 512
+__global__ void __launch_bounds__(256) column_sums_reduce_kernel(const float* __restrict__ partial,
+                                                                 float* __restrict__ out, int C, int chunks, int pitch) {
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int l = threadIdx.x & 31;
   float a = 0.f;
-  for (int k = 0; k < chunks; ++k) a += partial[(long long)k * pitch + c];
-  out[c] = a;
+  if (c < C)
+    for (int k = l; k < chunks; k += 32) a += partial[(long long)k * pitch + c];
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (c < C && l == 0) out[c] = a;
 }
 
 extern "C" long long ffa_column_sums_workspace_bytes(long long rows, int C) {
@@ -1115,7 +1130,7 @@ extern "C" int ffa_column_sums(int dtype, const void* x, float* out, long long r
   else
     hipLaunchKernelGGL(column_sums_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (float*)workspace, rows, C,
                        rpc);
-  hipLaunchKernelGGL(column_sums_reduce_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(column_sums_reduce_kernel, dim3((unsigned)((C + 7) / 8)), dim3(256), 0, stream,
                      (const float*)workspace, out, C, chunks, C);
   return ffa_check_launch("column_sums");
 }
@@ -1467,7 +1482,7 @@ extern "C" int ffa_window_attention_bwd(int dtype, const void* qkv, const void* 
     hipLaunchKernelGGL(column_sums_kernel<float>, dim3((unsigned)((pitch / 8 + 31) / 32), (unsigned)chunks), dim3(256), 0,
                        stream, (const float*)table_partial, red, nwin, pitch, rpc);
     const int TSH = (2 * ws - 1) * (2 * ws - 1) * heads;
-    hipLaunchKernelGGL(column_sums_reduce_kernel, dim3((unsigned)((TSH + 255) / 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(column_sums_reduce_kernel, dim3((unsigned)((TSH + 7) / 8)), dim3(256), 0, stream,
                        (const float*)red, dtable, TSH, chunks, pitch);
   }
   if (pad_rows) {
@@ -1475,7 +1490,7 @@ extern "C" int ffa_window_attention_bwd(int dtype, const void* qkv, const void* 
     const long long rpc = (pad_rows + chunks - 1) / chunks;
     hipLaunchKernelGGL(column_sums_kernel<float>, dim3((unsigned)((3 * C / 8 + 31) / 32), (unsigned)chunks), dim3(256), 0,
                        stream, (const float*)pad_partial, red, pad_rows, 3 * C, rpc);
-    hipLaunchKernelGGL(column_sums_reduce_kernel, dim3((unsigned)((3 * C + 255) / 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(column_sums_reduce_kernel, dim3((unsigned)((3 * C + 7) / 8)), dim3(256), 0, stream,
                        (const float*)red, dbias_pad, 3 * C, chunks, 3 * C);
   } else {
     hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((3 * C + 255) / 256)), dim3(256), 0, stream, dbias_pad, 3 * C);
@@ -1513,4 +1528,65 @@ extern "C" int ffa_scale_rows(int dtype, const void* x, void* y, const float* ro
     hipLaunchKernelGGL(scale_rows_kernel<float>, dim3(tf_grid(items)), dim3(FFA_TF_THREADS), 0, stream, (const float*)x,
                        (float*)y, row_scale, rows, C, rows_per_scale);
   return ffa_check_launch("scale_rows");
+}
+
+// ---- F.interpolate(F.interpolate(x, 2x, bilinear), 1/2, bilinear) in one pass.  UPerNet's last FPN stage (the 0-channel
+// placeholder feature of a transformer encoder) upsamples the pyramid map to stride 2 without adding anything, and the
+// decoder then resizes it back to stride 4: the composition of the two align_corners=False resizes is the separable
+// 3-tap filter [1/8, 3/4, 1/8] with replicated edges (up[2i] = x[i-1]/4 + 3x[i]/4, up[2i+1] = 3x[i]/4 + x[i+1]/4,
+// down[i] = (up[2i] + up[2i+1]) / 2), a symmetric operator -- so its backward is the same kernel on the gradient.
+// Neither the stride-2 map (1 GB at batch 32) nor its gradient is ever written.  Input and output may both be channel
+// slices of wider tensors.
+template <typename T>
+__global__ void blur3_slice_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int x_pitch,
+                                   int x_off, int y_pitch, int y_off) {
+  const int CG = C / 8;
+  const long long total = (long long)B * H * W * CG;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % CG);
+    long long p = i / CG;
+    const long long pix = p;
+    const int xx = (int)(p % W);
+    p /= W;
+    const int yy = (int)(p % H);
+    const long long b = p / H;
+    const int ys[3] = {yy > 0 ? yy - 1 : 0, yy, yy < H - 1 ? yy + 1 : H - 1};
+    const int xs[3] = {xx > 0 ? xx - 1 : 0, xx, xx < W - 1 ? xx + 1 : W - 1};
+    const float wt[3] = {0.125f, 0.75f, 0.125f};
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float row[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) row[e] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float v[8];
+        ffa_load8<T>(x + ((b * H + ys[a]) * W + xs[c]) * x_pitch + x_off + g * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) row[e] += wt[c] * v[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += wt[a] * row[e];
+    }
+    ffa_store8<T>(y + pix * y_pitch + y_off + g * 8, acc);
+  }
+}
+
+extern "C" int ffa_updown2x_slice(int dtype, const void* x, void* y, int B, int H, int W, int C, int x_pitch, int x_off,
+                                  int y_pitch, int y_off, hipStream_t stream) {
+  FFA_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "updown2x_slice: bad arguments");
+  FFA_REQUIRE(x_pitch % 8 == 0 && x_off % 8 == 0 && x_off >= 0 && x_off + C <= x_pitch && y_pitch % 8 == 0 &&
+                  y_off % 8 == 0 && y_off >= 0 && y_off + C <= y_pitch, "updown2x_slice: slices do not fit their pitches");
+  const long long items = (long long)B * H * W * (C / 8);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(blur3_slice_kernel<ffa_bf16>, dim3(tf_grid(items)), dim3(FFA_TF_THREADS), 0, stream,
+                       (const ffa_bf16*)x, (ffa_bf16*)y, B, H, W, C, x_pitch, x_off, y_pitch, y_off);
+  else
+    hipLaunchKernelGGL(blur3_slice_kernel<float>, dim3(tf_grid(items)), dim3(FFA_TF_THREADS), 0, stream, (const float*)x,
+                       (float*)y, B, H, W, C, x_pitch, x_off, y_pitch, y_off);
+  return ffa_check_launch("updown2x_slice");
 }

@@ -84,6 +84,7 @@ SIGNATURES = {
     "ffa_layer_norm_bwd_workspace_bytes": (_ll, [_ll, _i]),
     "ffa_layer_norm_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _p, _ll, _p]),
     "ffa_scale_rows": (_i, [_i, _p, _p, _p, _ll, _i, _i, _p]),
+    "ffa_updown2x_slice": (_i, [_i, _p, _p] + [_i] * 8 + [_p]),
     "ffa_column_sums_workspace_bytes": (_ll, [_ll, _i]),
     "ffa_column_sums": (_i, [_i, _p, _p, _ll, _i, _p, _ll, _p]),
     "ffa_patch_merge_norm_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _ll, _p]),

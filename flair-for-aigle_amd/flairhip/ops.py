@@ -1125,3 +1125,18 @@ def column_sums(x: torch.Tensor) -> torch.Tensor:
     _l.check(lib.ffa_column_sums(_dt(x), x.data_ptr(), out.data_ptr(), rows, C, ws.data_ptr(), ws.numel(), _stream()),
              "column_sums")
     return out
+
+
+def updown2x_slice(x: torch.Tensor, channels: int, x_offset: int = 0, out: Optional[torch.Tensor] = None,
+                   offset: int = 0) -> torch.Tensor:
+    """bilinear x2 then bilinear x1/2 (align_corners=False) of x[..., x_offset:x_offset+channels] in one pass, written to
+    out[..., offset:offset+channels] (dense output when out is None); the operator is symmetric (its own backward)"""
+    _chk_nhwc(x, "updown2x_slice input")
+    B, H, W, P = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, channels), dtype=x.dtype, device=x.device)
+    if out.shape[:3] != (B, H, W) or out.dtype != x.dtype or not out.is_contiguous():
+        raise ValueError("updown2x_slice: destination does not match")
+    _l.check(_l.load().ffa_updown2x_slice(_dt(x), x.data_ptr(), out.data_ptr(), B, H, W, channels, P, x_offset,
+                                          out.shape[-1], offset, _stream()), "updown2x_slice")
+    return out

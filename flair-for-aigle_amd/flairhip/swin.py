@@ -345,18 +345,23 @@ class _AdaptivePool(torch.autograd.Function):
 
 
 class _ResizeCat(torch.autograd.Function):
-    """cat([bilinear(t, out_hw) for t in tensors], channel) assembled in place (align_corners=False)"""
+    """cat([bilinear(t, out_hw) for t in tensors], channel) assembled in place (align_corners=False).  updown_last: one
+    more slice = the LAST tensor upsampled x2 and resized back (UPerNet's placeholder FPN stage), as a 3-tap filter"""
 
     @staticmethod
-    def forward(ctx, out_hw, *tensors):
+    def forward(ctx, out_hw, updown_last, *tensors):
         B = tensors[0].shape[0]
         widths = [t.shape[-1] for t in tensors]
-        out = torch.empty((B, out_hw[0], out_hw[1], sum(widths)), dtype=tensors[0].dtype, device=tensors[0].device)
+        total = sum(widths) + (widths[-1] if updown_last else 0)
+        out = torch.empty((B, out_hw[0], out_hw[1], total), dtype=tensors[0].dtype, device=tensors[0].device)
         off = 0
         for t, c in zip(tensors, widths):
             ops.bilinear_slice(t, out_hw, out=out, offset=off)
             off += c
+        if updown_last:
+            ops.updown2x_slice(tensors[-1], widths[-1], out=out, offset=off)
         ctx.shapes = [(t.shape[1], t.shape[2], t.shape[3]) for t in tensors]
+        ctx.updown_last = updown_last
         return out
 
     @staticmethod
@@ -364,9 +369,12 @@ class _ResizeCat(torch.autograd.Function):
         dy = dy.contiguous()
         grads, off = [], 0
         for i, (h, w, c) in enumerate(ctx.shapes):
-            grads.append(ops.bilinear_slice_bwd(dy, (h, w), c, offset=off) if ctx.needs_input_grad[i + 1] else None)
+            grads.append(ops.bilinear_slice_bwd(dy, (h, w), c, offset=off) if ctx.needs_input_grad[i + 2] else None)
             off += c
-        return (None, *grads)
+        if ctx.updown_last and grads[-1] is not None:
+            h, w, c = ctx.shapes[-1]
+            grads[-1] = grads[-1] + ops.updown2x_slice(dy, c, x_offset=off)  # the filter is its own transpose
+        return (None, None, *grads)
 
 
 class _ResizeAdd(torch.autograd.Function):
@@ -536,6 +544,12 @@ class HipUPerNetDecoder(nn.Module):
             if isinstance(m, hnn.HipConv2d):
                 nn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="relu")
 
+    @staticmethod
+    def _is_updown(prev: torch.Tensor, size, target) -> bool:
+        """the placeholder FPN stage doubles `prev` and the decoder resizes it straight back to `prev`'s own size"""
+        h, w = prev.shape[1], prev.shape[2]
+        return tuple(size) == (2 * h, 2 * w) and tuple(target) == (h, w)
+
     def _forward_train(self, *features: torch.Tensor) -> torch.Tensor:
         """the same graph through autograd nodes (training-mode BatchNorm inside conv_bn_act)"""
         H, W = features[0].shape[1], features[0].shape[2]
@@ -545,13 +559,17 @@ class HipUPerNetDecoder(nn.Module):
         h, w = x.shape[1], x.shape[2]
         pooled = [hnn.conv_bn_act(_AdaptivePool.apply(x, s), blk[1][0], blk[1][1], relu=True)
                   for s, blk in zip(self.sizes, self.psp.blocks)]
-        cat = _ResizeCat.apply((h, w), x, *pooled)
+        cat = _ResizeCat.apply((h, w), False, x, *pooled)
         fpn = [hnn.conv_bn_act(cat, self.psp.out_conv[0], self.psp.out_conv[1], relu=True)]
+        updown = False
         for f, stage in zip(feats[1:], self.fpn_stages):
             size = (f.shape[1], f.shape[2])
+            if f.shape[-1] == 0 and self._is_updown(fpn[-1], size, target):
+                updown = True  # placeholder stage: x2 up, nothing added, resized back below -- never materialised
+                continue
             lat = hnn.conv_bn_act(f, stage.skip_conv[0], stage.skip_conv[1], relu=True) if f.shape[-1] != 0 else None
             fpn.append(_ResizeAdd.apply(fpn[-1], lat, size, False))
-        wide = _ResizeCat.apply(target, *fpn)
+        wide = _ResizeCat.apply(target, updown, *fpn)
         return hnn.conv_bn_act(wide, self.fpn_bottleneck[0], self.fpn_bottleneck[1], relu=True)
 
     def forward(self, *features: torch.Tensor) -> torch.Tensor:
@@ -571,17 +589,22 @@ class HipUPerNetDecoder(nn.Module):
             ops.bilinear_slice(p, (h, w), out=cat, offset=C + i * q)
         top = hnn.conv_bn_act(cat, self.psp.out_conv[0], self.psp.out_conv[1], relu=True)
         fpn = [top]
+        updown = False
         for f, stage in zip(feats[1:], self.fpn_stages):
             size = (f.shape[1], f.shape[2])
             if f.shape[-1] != 0:
                 lat = hnn.conv_bn_act(f, stage.skip_conv[0], stage.skip_conv[1], relu=True)
                 fpn.append(ops.bilinear_slice(fpn[-1], size, addend=lat))
+            elif self._is_updown(fpn[-1], size, target):
+                updown = True  # x2 up + resize back = one 3-tap filter pass below; the stride-2 map is never written
             else:
                 fpn.append(ops.bilinear_slice(fpn[-1], size))
         P = self.pyramid
-        wide = torch.empty((B, target[0], target[1], len(fpn) * P), dtype=x.dtype, device=x.device)
+        wide = torch.empty((B, target[0], target[1], (len(fpn) + int(updown)) * P), dtype=x.dtype, device=x.device)
         for i, f in enumerate(fpn):
             ops.bilinear_slice(f, target, out=wide, offset=i * P)
+        if updown:
+            ops.updown2x_slice(fpn[-1], P, out=wide, offset=len(fpn) * P)
         return hnn.conv_bn_act(wide, self.fpn_bottleneck[0], self.fpn_bottleneck[1], relu=True)
 
 

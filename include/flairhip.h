@@ -229,6 +229,11 @@ int ffa_bilinear_slice(int dtype, const void* x, const void* addend, void* y, in
 /* y[m] = x[m] * row_scale[m / rows_per_scale] (DropPath factor on a gradient ahead of the weight / bias reductions) */
 int ffa_scale_rows(int dtype, const void* x, void* y, const float* row_scale, long long rows, int C, int rows_per_scale,
                    ffa_stream_t stream);
+/* bilinear x2 followed by bilinear x1/2 (both align_corners=False) as one separable 3-tap filter with replicated edges:
+ * UPerNet's placeholder FPN stage + the resize back to stride 4; symmetric, so it is its own backward.  x / y are channel
+ * slices [x_off, x_off + C) / [y_off, y_off + C) of tensors with pitches x_pitch / y_pitch and the same [B][H][W] */
+int ffa_updown2x_slice(int dtype, const void* x, void* y, int B, int H, int W, int C, int x_pitch, int x_off, int y_pitch,
+                       int y_off, ffa_stream_t stream);
 /* out[c] = sum_m x[m][c] (f32): nn.Linear's bias gradient, any width; deterministic */
 long long ffa_column_sums_workspace_bytes(long long rows, int C);
 int ffa_column_sums(int dtype, const void* x, float* out, long long rows, int C, void* workspace,

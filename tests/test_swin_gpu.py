@@ -573,3 +573,26 @@ def test_swin_training_reduces_the_loss_and_drop_path_is_stochastic():
     assert not torch.equal(y1, y2)
     with pytest.raises(NotImplementedError):
         model(ops.nchw_to_nhwc(x, torch.float32, ops.pad_channels(3)))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("hw", [(8, 8), (5, 12), (1, 3)])
+def test_updown2x_slice_is_the_two_resizes_and_its_own_transpose(dtype, hw):
+    """UPerNet's placeholder FPN stage: F.interpolate(x2) then F.interpolate(back) == one replicate-padded 3-tap filter"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(17)
+    C = 16
+    xw = torch.randn(2, *hw, 40, generator=g).to(dtype)
+    xr = xw[..., 8:24].float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    up = F.interpolate(xr, size=(2 * hw[0], 2 * hw[1]), mode="bilinear", align_corners=False)
+    ref = F.interpolate(up, size=hw, mode="bilinear", align_corners=False)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    wide = torch.full((2, *hw, 32), 3.0, dtype=dtype, device=DEV)
+    ops.updown2x_slice(xw.to(DEV), C, x_offset=8, out=wide, offset=16)
+    tol = 2e-6 if dtype == torch.float32 else 2e-2
+    got = wide.float().cpu()
+    assert (got[..., 16:] - ref.detach().permute(0, 2, 3, 1)).abs().max().item() <= tol
+    assert torch.all(got[..., :16] == 3.0)
+    dx = ops.updown2x_slice(dy.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV), C).float().cpu()
+    assert (dx - xr.grad.permute(0, 2, 3, 1)).abs().max().item() <= (2e-6 if dtype == torch.float32 else 3e-2)
