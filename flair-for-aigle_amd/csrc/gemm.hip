@@ -250,3 +250,246 @@ extern "C" int ffa_linear(int dtype, const void* a, long long lda, const void* w
                           long long ldr, void* out, long long ldc, int M, int K, int N, int act, hipStream_t stream) {
   return ffa_linear_ex(dtype, a, lda, w, bias, residual, ldr, out, ldc, M, K, N, act, nullptr, 0, nullptr, 0, stream);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM of nn.Linear:  dW[n][k] = sum_m dy[m][n] * x[m][k]   (f32 out, [N][K] like nn.Linear.weight)
+//
+// The contraction runs over the TOKEN index m, the slow dimension of both row-major operands, so the MFMA fragments
+// (8 consecutive m per lane) are transposed reads: the [64 m][128 n] / [64 m][128 k] tiles are staged row-major in LDS
+// and read with ds_read_b64_tr_b16 (4 tokens x 16 columns per 16-lane group and instruction).  Row pitch 288 bytes and
+// the k-slot order  slot 8g + j  <->  token (j < 4 ? 4g + j : 16 + 4g + j - 4)  of a 32-token step put the 8 rows a
+// 32-lane half touches on 8 disjoint bank octets (conflict-free).  Block: 128 n x 128 k of dW over a contiguous range of
+// 64-token chunks (split over the tokens: [split][N][K] f32 slabs in the workspace, summed in a fixed order by
+// gemm_tn_reduce_kernel -- deterministic); 4 waves as 2 x 2, 64 x 64 each; double-buffered LDS, register prefetch.
+// Bound: HBM at the thin stages (each operand is read once; the output is tiny), MFMA for the 768-wide ones.
+struct GemmTnArgs {
+  const ffa_bf16* dy;  // [M][ldy]
+  const ffa_bf16* x;   // [M][ldx]
+  float* slab;         // [splits][N][K]
+  float* bias_slab;    // nullable: [splits][N] column sums of dy (nn.Linear's bias gradient), written by the bk = 0 blocks
+  long long ldy, ldx;
+  int M, N, K, nblk_n, nblk_k, chunks_per_split;
+};
+
+namespace {
+constexpr int TBM = 64;            // tokens per chunk
+constexpr int TPITCH = 288;        // bytes per staged row (128 columns + 32 pad)
+constexpr int TIMG = 2 * TBM * TPITCH;
+}  // namespace
+
+__device__ __forceinline__ ffa_s16x4 gemm_read_tr16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) ffa_s16x4*)(const_cast<unsigned char*>(p)));
+}
+
+__global__ void __launch_bounds__(256, 2) gemm_tn_bf16_kernel(GemmTnArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TIMG];
+  int id = blockIdx.x;
+  const int tiles = g.nblk_n * g.nblk_k;
+  const int split = id / tiles;
+  id -= split * tiles;
+  const int bn = id / g.nblk_k, bk = id % g.nblk_k;
+  const int n0 = bn * 128, k0 = bk * 128;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int grp = lane >> 4;
+
+  // staging: a chunk is 64 rows x 16 pieces of 16 bytes per operand = 1024 pieces, 4 per thread and operand
+  const int pc = tid & 15;  // 16-byte piece (8 columns) of the 128-column tile row
+  int ycol = n0 + pc * 8, xcol = k0 + pc * 8;
+  if (ycol > g.N - 8) ycol = g.N - 8;  // past the matrix: any valid piece, its products land outside dW
+  if (xcol > g.K - 8) xcol = g.K - 8;
+  const long long c0 = (long long)split * g.chunks_per_split;
+  long long c1 = c0 + g.chunks_per_split;
+  const long long nchunks = ((long long)g.M + TBM - 1) / TBM;
+  if (c1 > nchunks) c1 = nchunks;
+  ffa_u32x4 ry[4], rx[4];
+  // bias gradient: this thread's pieces always cover the same 8 columns of dy (pc is fixed), so their column sums
+  // accumulate in registers as the chunks stream through
+  const bool want_bias = g.bias_slab != nullptr && bk == 0;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto load_regs = [&](long long c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      long long m = c * TBM + (tid >> 4) + 16 * j;
+      const bool live = m < g.M;
+      if (!live) m = g.M - 1;
+      ry[j] = *reinterpret_cast<const ffa_u32x4*>(g.dy + m * g.ldy + ycol);
+      rx[j] = *reinterpret_cast<const ffa_u32x4*>(g.x + m * g.ldx + xcol);
+      if (!live) ry[j] = ffa_u32x4{0u, 0u, 0u, 0u};  // rows past M contribute nothing
+    }
+  };
+  auto store_lds = [&](int buf) {
+    unsigned char* img = smem + buf * TIMG;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = (tid >> 4) + 16 * j;
+      *reinterpret_cast<ffa_u32x4*>(img + r * TPITCH + pc * 16) = ry[j];
+      *reinterpret_cast<ffa_u32x4*>(img + TBM * TPITCH + r * TPITCH + pc * 16) = rx[j];
+      if (want_bias) {  // block-uniform
+        float v[8];
+        ffa_load8<ffa_bf16>(reinterpret_cast<const ffa_bf16*>(&ry[j]), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] += v[e];
+      }
+    }
+  };
+  ffa_f32x4 acc[4][4];  // [n tile][k tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = ffa_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (c0 < c1) {
+    load_regs(c0);
+    store_lds(0);
+    if (c0 + 1 < c1) load_regs(c0 + 1);
+  }
+  __syncthreads();
+  // transposed-read address of this lane inside a 4-token x 16-column block: token (lane / 4) % 4, columns 4 (lane % 4)
+  const int tr_off = ((lane >> 2) & 3) * TPITCH + (lane & 3) * 8;
+  const int yb = grp * 4 * TPITCH + (wn * 64) * 2 + tr_off;                  // + step * 32 rows, + tile * 32 bytes
+  const int xb = TBM * TPITCH + grp * 4 * TPITCH + (wk * 64) * 2 + tr_off;
+  int buf = 0;
+  for (long long c = c0; c < c1; ++c) {
+    if (c + 1 < c1) store_lds(buf ^ 1);
+    if (c + 2 < c1) load_regs(c + 2);
+    const unsigned char* img = smem + buf * TIMG;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {  // two 32-token steps per chunk
+      ffa_bf16x8 fy[4], fx[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned char* py = img + yb + st * 32 * TPITCH + i * 32;
+        const unsigned char* px = img + xb + st * 32 * TPITCH + i * 32;
+        const ffa_s16x4 y0 = gemm_read_tr16(py), y1 = gemm_read_tr16(py + 16 * TPITCH);
+        const ffa_s16x4 x0 = gemm_read_tr16(px), x1 = gemm_read_tr16(px + 16 * TPITCH);
+        ffa_u32x4 vy, vx;
+        vy.x = __builtin_bit_cast(ffa_u32x2, y0).x; vy.y = __builtin_bit_cast(ffa_u32x2, y0).y;
+        vy.z = __builtin_bit_cast(ffa_u32x2, y1).x; vy.w = __builtin_bit_cast(ffa_u32x2, y1).y;
+        vx.x = __builtin_bit_cast(ffa_u32x2, x0).x; vx.y = __builtin_bit_cast(ffa_u32x2, x0).y;
+        vx.z = __builtin_bit_cast(ffa_u32x2, x1).x; vx.w = __builtin_bit_cast(ffa_u32x2, x1).y;
+        fy[i] = __builtin_bit_cast(ffa_bf16x8, vy);
+        fx[i] = __builtin_bit_cast(ffa_bf16x8, vx);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (want_bias) {  // 16 row-threads per column piece -> one sum per column, through LDS (free after the loop)
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + pc * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 128) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v += red[r * 128 + tid];
+      // columns clamped to the matrix edge were loaded twice: only the piece's own columns are written
+      if (n0 + tid < g.N) g.bias_slab[(long long)split * g.N + n0 + tid] = v;
+    }
+  }
+  // D[row n = 4 grp + e][col k = lane % 16] -> slab[split][n][k]
+  float* out = g.slab + (long long)split * g.N * g.K;
+  const int kc = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + wk * 64 + j * 16 + kc;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = n0 + wn * 64 + i * 16 + grp * 4 + e;
+        if (n < g.N && k < g.K) out[(long long)n * g.K + k] = acc[i][j][e];
+      }
+    }
+}
+
+// dw[i] (+)= sum_s slab[s][i]: a block owns 8 consecutive float4 columns; its 32 split-lanes take the slabs
+// s = lane, lane + 32, ... (adjacent threads read adjacent 16-byte pieces of one slab: full 128-byte lines), then the
+// lanes are combined by xor-shuffles inside each wave and across the four waves through LDS -- a fixed order
+__global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                             long long nk, int splits, int accumulate) {
+  __shared__ float4 part[4][8];
+  const int col = threadIdx.x & 7, sl = threadIdx.x >> 3;  // split lane 0..31; a wave holds 8 of them
+  const long long i = (blockIdx.x * 8LL + col) * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < nk)
+    for (int s = sl; s < splits; s += 32) {
+      const float4 v = *reinterpret_cast<const float4*>(slab + (long long)s * nk + i);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    a.x += __shfl_xor(a.x, o, 64);
+    a.y += __shfl_xor(a.y, o, 64);
+    a.z += __shfl_xor(a.z, o, 64);
+    a.w += __shfl_xor(a.w, o, 64);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < 8) part[wave][col] = a;
+  __syncthreads();
+  if (threadIdx.x < 8 && i < nk) {
+    float4 r = accumulate ? *reinterpret_cast<const float4*>(dw + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      r.x += part[w][col].x; r.y += part[w][col].y; r.z += part[w][col].z; r.w += part[w][col].w;
+    }
+    *reinterpret_cast<float4*>(dw + i) = r;
+  }
+}
+
+static void gemm_tn_plan(int M, int N, int K, int* nblk_n, int* nblk_k, int* splits, int* cps) {
+  *nblk_n = (N + 127) / 128;
+  *nblk_k = (K + 127) / 128;
+  const long long tiles = (long long)*nblk_n * *nblk_k;
+  const long long chunks = ((long long)M + TBM - 1) / TBM;
+  long long s = (768 + tiles - 1) / tiles;  // about three blocks per CU
+  if (s > chunks) s = chunks;
+  if (s < 1) s = 1;
+  long long per = (chunks + s - 1) / s;
+  s = (chunks + per - 1) / per;
+  *splits = (int)s;
+  *cps = (int)per;
+}
+
+extern "C" long long ffa_linear_wgrad_workspace_bytes(int M, int N, int K) {
+  int a, b, s, c;
+  gemm_tn_plan(M, N, K, &a, &b, &s, &c);
+  return (long long)s * ((long long)N * K + N) * (long long)sizeof(float);
+}
+
+extern "C" int ffa_linear_wgrad(int dtype, const void* x, long long ldx, const void* dy, long long ldy, float* dw,
+                                float* dbias, int M, int K, int N, int accumulate, void* workspace,
+                                long long workspace_bytes, hipStream_t stream) {
+  FFA_REQUIRE(dtype == FFA_BF16, "linear_wgrad: bf16 only");
+  FFA_REQUIRE(x && dy && dw && M > 0 && K >= 8 && N >= 8 && K % 8 == 0 && N % 8 == 0, "linear_wgrad: bad arguments");
+  FFA_REQUIRE(ldx >= K && ldx % 8 == 0 && ldy >= N && ldy % 8 == 0, "linear_wgrad: row pitches must cover the rows");
+  FFA_REQUIRE(((long long)N * K) % 4 == 0 && N % 4 == 0, "linear_wgrad: N * K and N must be multiples of 4");
+  if (!workspace || workspace_bytes < ffa_linear_wgrad_workspace_bytes(M, N, K)) {
+    ffa_set_error("linear_wgrad: workspace of %lld bytes needed", ffa_linear_wgrad_workspace_bytes(M, N, K));
+    return FFA_ERR_WORKSPACE;
+  }
+  GemmTnArgs g;
+  g.dy = (const ffa_bf16*)dy;
+  g.x = (const ffa_bf16*)x;
+  g.slab = (float*)workspace;
+  g.ldy = ldy; g.ldx = ldx;
+  g.M = M; g.N = N; g.K = K;
+  int splits;
+  gemm_tn_plan(M, N, K, &g.nblk_n, &g.nblk_k, &splits, &g.chunks_per_split);
+  g.bias_slab = dbias ? g.slab + (long long)splits * N * K : nullptr;
+  const long long blocks = (long long)g.nblk_n * g.nblk_k * splits;
+  hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g);
+  const long long nk = (long long)N * K;
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((nk / 4 + 7) / 8)), dim3(256), 0, stream,
+                     (const float*)workspace, dw, nk, splits, accumulate ? 1 : 0);
+  if (dbias)
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((N / 4 + 7) / 8)), dim3(256), 0, stream,
+                       (const float*)g.bias_slab, dbias, (long long)N, splits, accumulate ? 1 : 0);
+  return ffa_check_launch("linear_wgrad");
+}

@@ -79,6 +79,8 @@ SIGNATURES = {
     "ffa_linear": (_i, [_i, _p, _ll, _p, _p, _p, _ll, _p, _ll, _i, _i, _i, _i, _p]),
     "ffa_space_to_depth": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ffa_linear_ex": (_i, [_i, _p, _ll, _p, _p, _p, _ll, _p, _ll, _i, _i, _i, _i, _p, _ll, _p, _i, _p]),
+    "ffa_linear_wgrad_workspace_bytes": (_ll, [_i, _i, _i]),
+    "ffa_linear_wgrad": (_i, [_i, _p, _ll, _p, _ll, _p, _p, _i, _i, _i, _i, _p, _ll, _p]),
     "ffa_layer_norm": (_i, [_i, _p, _p, _p, _p, _p, _ll, _i, _f, _p]),
     "ffa_patch_merge_norm": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "ffa_layer_norm_bwd_workspace_bytes": (_ll, [_ll, _i]),

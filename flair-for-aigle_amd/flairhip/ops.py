@@ -1140,3 +1140,23 @@ def updown2x_slice(x: torch.Tensor, channels: int, x_offset: int = 0, out: Optio
     _l.check(_l.load().ffa_updown2x_slice(_dt(x), x.data_ptr(), out.data_ptr(), B, H, W, channels, P, x_offset,
                                           out.shape[-1], offset, _stream()), "updown2x_slice")
     return out
+
+
+def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False,
+                 with_bias: bool = False):
+    """dW f32 [N, K] = dy^T x over all rows of the contiguous bf16 tensors x [..., K] and dy [..., N]; with_bias also
+    returns db f32 [N] = column sums of dy from the same pass: (dW, db)"""
+    if x.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16 or not x.is_contiguous() or not dy.is_contiguous():
+        raise ValueError("linear_wgrad: contiguous bf16 operands only")
+    K, N = x.shape[-1], dy.shape[-1]
+    M = x.numel() // K
+    if dy.numel() // N != M:
+        raise ValueError("linear_wgrad: x and dy must have the same number of rows")
+    lib = _l.load()
+    if out is None:
+        out = torch.empty((N, K), dtype=torch.float32, device=x.device)
+    db = torch.empty(N, dtype=torch.float32, device=x.device) if with_bias else None
+    ws = workspace(lib.ffa_linear_wgrad_workspace_bytes(M, N, K), x.device, "lin_wgrad")
+    _l.check(lib.ffa_linear_wgrad(_dt(x), x.data_ptr(), K, dy.data_ptr(), N, out.data_ptr(), _ptr(db), M, K, N,
+                                  1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()), "linear_wgrad")
+    return (out, db) if with_bias else out

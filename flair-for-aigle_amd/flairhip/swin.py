@@ -22,8 +22,8 @@ bf16 mode uses the hand-written token GEMM (csrc/gemm.hip); the f32 parity mode 
 
 Training (bf16 only): every block half / merging / embedding / decoder resampling step is one autograd node whose
 backward runs on the same library -- input gradients through the token GEMM with the TRANSPOSED weight (gelu' of the kept
-pre-activation and the DropPath factor in its epilogue), weight gradients through the 1x1 instance of ffa_conv_wgrad
-(deterministic split-K over the tokens), bias gradients through ffa_channel_sums, ffa_layer_norm_bwd (with the residual
+pre-activation and the DropPath factor in its epilogue), weight gradients through ffa_linear_wgrad (transposed-operand
+GEMM, deterministic split over the tokens), bias gradients through ffa_channel_sums, ffa_layer_norm_bwd (with the residual
 gradient added in the same pass), ffa_window_attention_bwd, ffa_bilinear_slice_bwd, ffa_adaptive_avg_pool_bwd.  timm's
 DropPath (stochastic depth, drop_path_rate = 0.1 by default, linearly increasing over the blocks) is the per-sample
 row scale of the residual GEMMs.  The f32 parity mode covers the evaluation forward only (the attention backward is a
@@ -182,11 +182,14 @@ def _wt(cache: _Operands, tag: str, weight: torch.Tensor):
     return cache.get(tag + ":wt", (weight,), torch.bfloat16, build)
 
 
+def _wgrad_bias(x: torch.Tensor, dy: torch.Tensor):
+    """(dW [N, K], db [N]) f32 of an nn.Linear from one pass over x and dy"""
+    return ops.linear_wgrad(x, dy, with_bias=True)
+
+
 def _wgrad(x: torch.Tensor, dy: torch.Tensor, n_out: int, n_in: int) -> torch.Tensor:
-    """dW [n_out, n_in] f32 = dy^T x over all tokens (ffa_conv_wgrad's 1x1 instance, deterministic split-K)"""
-    x4 = x if x.dim() == 4 else x.reshape(1, 1, -1, x.shape[-1])
-    d4 = dy if dy.dim() == 4 else dy.reshape(1, 1, -1, dy.shape[-1])
-    return ops.conv_wgrad(x4, d4, n_out, n_in, 1, 1, 1, 0).view(n_out, n_in)
+    """dW [n_out, n_in] f32 = dy^T x over all tokens (ffa_linear_wgrad: transposed-operand GEMM, deterministic split)"""
+    return ops.linear_wgrad(x, dy)
 
 
 def _colsum(dy: torch.Tensor) -> torch.Tensor:
@@ -230,14 +233,13 @@ class _AttnHalf(torch.autograd.Function):
         dys = dy if rs is None else ops.scale_rows(dy, rs, ctx.rps)
         _, wpt = _wt(enc._ops, tag + "proj", wproj)
         datt = ops.linear(dys, wpt)
-        dwp = _wgrad(att, dys, C, C)
-        dbp = _colsum(dys)
+        dwp, dbp = _wgrad_bias(att, dys)
         dqkv, dtable, dbpad = ops.window_attention_bwd(qkv, datt, bqkv.detach(), table.detach().contiguous(), blk.heads,
                                                        blk.ws, blk.shift, ctx.scale)
         _, wqt = _wt(enc._ops, tag + "qkv", wqkv)
         dh = ops.linear(dqkv, wqt)
-        dwq = _wgrad(h, dqkv, 3 * C, C)
-        dbq = _colsum(dqkv) + dbpad
+        dwq, dbq = _wgrad_bias(h, dqkv)
+        dbq = dbq + dbpad
         dx, dg1, db1 = ops.layer_norm_bwd(x, dh, g1.detach(), stats, dres=dy)
         return dx, dg1, db1, dwq, dbq, dtable, dwp, dbp, None, None, None, None
 
@@ -270,12 +272,10 @@ class _MlpHalf(torch.autograd.Function):
         dys = dy if rs is None else ops.scale_rows(dy, rs, ctx.rps)
         _, w2t = _wt(enc._ops, tag + "fc2", w2)
         du = ops.linear(dys, w2t, act=ops.ACT_DGELU, aux=u)  # (dys W2) * gelu'(u)
-        dw2 = _wgrad(a, dys, C, 4 * C)
-        db2 = _colsum(dys)
+        dw2, db2 = _wgrad_bias(a, dys)
         _, w1t = _wt(enc._ops, tag + "fc1", w1)
         dh = ops.linear(du, w1t)
-        dw1 = _wgrad(h, du, 4 * C, C)
-        db1 = _colsum(du)
+        dw1, db1 = _wgrad_bias(h, du)
         dx, dg, db = ops.layer_norm_bwd(x, dh, g2.detach(), stats, dres=dy)
         return dx, dg, db, dw1, db1, dw2, db2, None, None, None, None
 
@@ -327,9 +327,8 @@ class _PatchEmbed(torch.autograd.Function):
         s2d, t, stats, g = ctx.saved_tensors
         ps, cp, dim, cin = ctx.geom
         dt, dg, db = ops.layer_norm_bwd(t, dy.contiguous(), g.detach(), stats)
-        dw2 = _wgrad(s2d, dt, dim, ps * ps * cp)
+        dw2, dbias = _wgrad_bias(s2d, dt)
         dw = dw2.view(dim, ps, ps, cp)[..., :cin].permute(0, 3, 1, 2).contiguous()
-        dbias = _colsum(dt)
         return None, dw, dbias, dg, db, None
 
 

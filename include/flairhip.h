@@ -185,6 +185,12 @@ int ffa_linear(int dtype, const void* a, long long lda, const void* w, const flo
 int ffa_linear_ex(int dtype, const void* a, long long lda, const void* w, const float* bias, const void* residual,
                   long long ldr, void* out, long long ldc, int M, int K, int N, int act, void* aux, long long ldaux,
                   const float* row_scale, int rows_per_scale, ffa_stream_t stream);
+/* nn.Linear's weight gradient dW[n][k] = sum_m dy[m][n] x[m][k] (f32 [N][K]; accumulate != 0 adds to dw): transposed-
+ * operand MFMA GEMM over the tokens, split over token ranges with a fixed-order reduction (deterministic) */
+long long ffa_linear_wgrad_workspace_bytes(int M, int N, int K);
+int ffa_linear_wgrad(int dtype, const void* x, long long ldx, const void* dy, long long ldy, float* dw,
+                     float* dbias /* nullable: [N] column sums of dy from the same pass */, int M, int K, int N,
+                     int accumulate, void* workspace, long long workspace_bytes, ffa_stream_t stream);
 /* PatchEmbed's Conv2d(kernel = stride = ps) as a gather: out[b][y][x][(dy*ps + dx)*C + c] = in[b][y*ps+dy][x*ps+dx][c] */
 int ffa_space_to_depth(int dtype, const void* in, void* out, int B, int Ho, int Wo, int C, int ps, ffa_stream_t stream);
 /* nn.LayerNorm(C) over rows of C contiguous channels; stats (nullable) receives (mean, rstd) per row for the backward pass */

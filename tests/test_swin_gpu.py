@@ -596,3 +596,23 @@ def test_updown2x_slice_is_the_two_resizes_and_its_own_transpose(dtype, hw):
     assert torch.all(got[..., :16] == 3.0)
     dx = ops.updown2x_slice(dy.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV), C).float().cpu()
     assert (dx - xr.grad.permute(0, 2, 3, 1)).abs().max().item() <= (2e-6 if dtype == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize("M,K,N", [(256, 96, 288), (1000, 96, 96), (4096, 384, 96), (2048, 768, 3072), (70, 128, 8),
+                                    (8192, 256, 128), (333, 200, 136)])
+def test_linear_wgrad_matches_torch(M, K, N):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(M + K + N)
+    x, dy = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(M, N, generator=g))
+    ref = dy.float().t() @ x.float()
+    dw = ops.linear_wgrad(x.to(DEV), dy.to(DEV))
+    assert dw.shape == (N, K)
+    assert (dw.cpu() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    again = ops.linear_wgrad(x.to(DEV), dy.to(DEV))
+    assert torch.equal(dw, again)  # fixed summation order
+    acc = ops.linear_wgrad(x.to(DEV), dy.to(DEV), out=dw.clone(), accumulate=True)
+    assert (acc.cpu() - 2 * ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item())
+    dw2, db = ops.linear_wgrad(x.to(DEV), dy.to(DEV), with_bias=True)  # nn.Linear's bias gradient from the same pass
+    assert torch.equal(dw2, dw)
+    ref_b = dy.float().sum(0)
+    assert db.shape == (N,) and (db.cpu() - ref_b).abs().max().item() <= 1e-3 * max(1.0, ref_b.abs().max().item())
