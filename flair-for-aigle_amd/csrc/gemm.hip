@@ -15,6 +15,7 @@
 // chunk c+1 moves registers -> LDS (other image) while chunk c feeds the matrix pipe: ONE barrier per 32 MFMAs per wave.
 // Bound: HBM for the thin early stages (K = 128: 1.5 flop per byte moved at stage 1), MFMA for K >= 512.
 #include "ffa_common.h"
+#include <stdlib.h>
 
 #define FFA_ACT_NONE 0
 #define FFA_ACT_GELU 1
@@ -215,6 +216,200 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same GEMM on a 256 x 256 block tile for the MFMA-bound shapes (K >= 256, N a multiple of 256 or large):
+// 8 waves as 2 (tokens) x 4 (features), 128 tokens x 64 features per wave (8 x 4 MFMA tiles, 128 accumulator VGPRs:
+// 2.7 MFMAs per ds_read_b128 instead of 2), BK = 32, operands streamed global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4 from inline asm: with the builtin hipcc stops counting lgkmcnt) into a
+// four-stage ring of (256 + 256) rows x 64 bytes, three tiles ahead, counted vmcnt (never 0 in the loop), one raw
+// s_barrier per 32 MFMAs per wave.  The DMA writes linearly (16 rows x 64 bytes per wave instruction), so the
+// bank-conflict swizzle is applied on the SOURCE side and again on the read: 16-byte chunk c of row r lives at chunk
+// c ^ f(r), f = [0, 3, 2, 1][(r >> 2) & 3] -- the four 16-lane groups of a ds_read_b128 (lanes {0-3, 12-15, 20-27}, ...)
+// then touch 16 distinct 16-byte slots of the 256-byte bank row.
+namespace {
+constexpr int HBM_ = 256, HBN_ = 256, HBK = 32;
+constexpr int HROWB = 64;                       // bytes per staged row
+constexpr int HSTAGE = (HBM_ + HBN_) * HROWB;   // 32 KB
+constexpr int HSTAGES = 4;
+}  // namespace
+
+__device__ __forceinline__ int gemm256_swz(int r) { return (4 - ((r >> 2) & 3)) & 3; }
+
+__device__ __forceinline__ void gemm_dma16(const unsigned char* src, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_base)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void gemm_wait_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(N) : "memory");
+}
+
+__global__ void __launch_bounds__(512, 1) gemm256_bf16_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[HSTAGES * HSTAGE];
+  const int nb = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int per = nb >> 3, rem = nb & 7, xcd = id & 7, loc = id >> 3;
+    id = xcd < rem ? xcd * (per + 1) + loc : rem * (per + 1) + (xcd - rem) * per + loc;
+  }
+  const int bm = id / g.nblk_n, bn = id % g.nblk_n;
+  const int m0 = bm * HBM_, n0 = bn * HBN_;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int n = lane & 15, grp = lane >> 4;
+
+  // DMA: this wave fills token rows [32 wave, 32 wave + 32) and feature rows [32 wave, +32) of a stage, 16 rows per
+  // instruction; lane i writes row i / 4, chunk i % 4 and therefore fetches chunk (i % 4) ^ f(row)
+  const unsigned char* src[4];
+  unsigned dst[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = wave * 32 + (j & 1) * 16 + (lane >> 2);   // row inside the 256-row operand tile
+    const int c = (lane & 3) ^ gemm256_swz(r);
+    if (j < 2) {
+      int row = m0 + r;
+      if (row > g.M - 1) row = g.M - 1;
+      src[j] = reinterpret_cast<const unsigned char*>(g.a + (long long)row * g.lda) + c * 16;
+    } else {
+      int row = n0 + r;
+      if (row > g.N - 1) row = g.N - 1;
+      src[j] = reinterpret_cast<const unsigned char*>(g.w + (long long)row * g.K) + c * 16;
+    }
+    dst[j] = (unsigned)((j < 2 ? 0 : HBM_ * HROWB) + (wave * 32 + (j & 1) * 16) * HROWB);
+  }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+  auto issue = [&](int t) {
+    const unsigned base = lds0 + (unsigned)((t & (HSTAGES - 1)) * HSTAGE);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      gemm_dma16(src[j] + (long long)t * (HBK * 2),
+                 (unsigned)__builtin_amdgcn_readfirstlane((int)(base + dst[j])));
+  };
+
+  ffa_f32x4 acc[4][8];  // [feature tile][token tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = ffa_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / HBK;
+  issue(0);
+  if (nk > 1) issue(1);
+  if (nk > 2) issue(2);
+  // fragment read offsets: row (tile * 16 + n), chunk grp ^ f(row); f depends on the row modulo 16 only
+  const int fsw = (grp ^ gemm256_swz(n)) * 16;
+  const int tok_off = (wm * 128 + n) * HROWB + fsw;
+  const int fea_off = HBM_ * HROWB + (wn * 64 + n) * HROWB + fsw;
+  for (int t = 0; t < nk; ++t) {
+    // tile t has landed for every wave once each wave's own pieces are retired and the barrier is passed; the
+    // barrier also says that everyone is done reading tile t - 1, whose stage tile t + 3 is about to overwrite
+    if (t + 2 < nk) gemm_wait_barrier<8>();
+    else if (t + 1 < nk) gemm_wait_barrier<4>();
+    else gemm_wait_barrier<0>();
+    if (t + 3 < nk) issue(t + 3);
+    const unsigned char* img = smem + (t & (HSTAGES - 1)) * HSTAGE;
+    ffa_bf16x8 fw[4], ft[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const ffa_bf16x8*>(img + fea_off + i * 16 * HROWB);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ft[j] = *reinterpret_cast<const ffa_bf16x8*>(img + tok_off + j * 16 * HROWB);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], ft[j], acc[i][j], 0, 0, 0);
+  }
+  __syncthreads();  // every wave is done with the ring: it becomes the epilogue's staging area
+
+  // ---- epilogue, two halves of 64 tokens per wave: registers -> LDS (bf16) -> whole 128-byte row segments
+  unsigned char* ep = smem + wave * (64 * GEP);
+  const int fcol0 = n0 + wn * 64;
+  const int fp = lane & 7;
+  const int col = fcol0 + fp * 8;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = fcol0 + i * 16 + grp * 4;
+      float b4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (g.bias && f < g.N) {
+        const float4 bv = *reinterpret_cast<const float4*>(g.bias + f);
+        b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[i][half * 4 + j][e] + b4[e];
+          if (g.act == FFA_ACT_GELU && !g.aux) v[e] = gemm_gelu(v[e]);
+        }
+        uint2 pk;
+        pk.x = ffa_pack_bf16x2(v[0], v[1]);
+        pk.y = ffa_pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(ep + (j * 16 + n) * GEP + (i * 16 + grp * 4) * 2) = pk;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tt = (lane >> 3) + 8 * j;
+      const int row = m0 + wm * 128 + half * 64 + tt;
+      if (row < g.M && col < g.N) {
+        ffa_u32x4 v = *reinterpret_cast<const ffa_u32x4*>(ep + tt * GEP + fp * 16);
+        if (g.residual || g.aux || g.row_scale) {  // block-uniform
+          float o[8];
+          ffa_load8<ffa_bf16>(reinterpret_cast<const ffa_bf16*>(&v), o);
+          if (g.aux) {
+            if (g.act == FFA_ACT_GELU) {
+              *reinterpret_cast<ffa_u32x4*>(g.aux + (long long)row * g.ldaux + col) = v;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = gemm_gelu(o[e]);
+            } else if (g.act == FFA_ACT_DGELU) {
+              float u[8];
+              ffa_load8<ffa_bf16>(g.aux + (long long)row * g.ldaux + col, u);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] *= gemm_dgelu(u[e]);
+            }
+          }
+          if (g.row_scale) {
+            const float sc = g.row_scale[row / g.rows_per_scale];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] *= sc;
+          }
+          if (g.residual) {
+            float r[8];
+            ffa_load8<ffa_bf16>(g.residual + (long long)row * g.ldr + col, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += r[e];
+          }
+          ffa_store8<ffa_bf16>(g.out + (long long)row * g.ldc + col, o);
+        } else {
+          *reinterpret_cast<ffa_u32x4*>(g.out + (long long)row * g.ldc + col) = v;
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// 256-tile kernel when the shape is MFMA-bound and fills the chip; FFA_GEMM_TILE=128|256 overrides (A/B runs)
+static bool gemm_use_256(int M, int K, int N) {
+  static const char* force = getenv("FFA_GEMM_TILE");
+  if (force && force[0] == '1') return false;
+  const bool ok = (K % HBK == 0) && K >= 64 && M >= 256 && N >= 128;
+  if (force && force[0] == '2') return ok;
+  if (!ok || K < 256) return false;
+  const long long blocks = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  const double waste = (double)(((N + 255) / 256) * 256) / (double)N;
+  return blocks >= 240 && waste <= 1.15;  // one 512-thread block per CU: fewer blocks than CUs leave the chip idle
+}
+
 extern "C" int ffa_linear_ex(int dtype, const void* a, long long lda, const void* w, const float* bias,
                              const void* residual, long long ldr, void* out, long long ldc, int M, int K, int N, int act,
                              void* aux, long long ldaux, const float* row_scale, int rows_per_scale,
@@ -239,6 +434,13 @@ extern "C" int ffa_linear_ex(int dtype, const void* a, long long lda, const void
   g.lda = lda; g.ldr = ldr; g.ldc = ldc; g.ldaux = ldaux;
   g.M = M; g.K = K; g.N = N; g.act = act;
   g.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+  if (gemm_use_256(M, K, N)) {
+    g.nblk_n = (N + HBN_ - 1) / HBN_;
+    const long long blocks = (long long)((M + HBM_ - 1) / HBM_) * g.nblk_n;
+    FFA_REQUIRE(blocks < (1LL << 31), "linear: grid too large");
+    hipLaunchKernelGGL(gemm256_bf16_kernel, dim3((unsigned)blocks), dim3(512), 0, stream, g);
+    return ffa_check_launch("linear");
+  }
   g.nblk_n = (N + GBN - 1) / GBN;
   const long long blocks = (long long)((M + GBM - 1) / GBM) * g.nblk_n;
   FFA_REQUIRE(blocks < (1LL << 31), "linear: grid too large");

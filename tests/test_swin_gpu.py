@@ -49,6 +49,33 @@ def test_linear_matches_torch(M, K, N, act, res):
         assert (y2.float().cpu() - ref2).abs().max().item() <= 2e-2 * max(1.0, ref2.abs().max().item())
 
 
+@pytest.mark.parametrize("M,K,N,act,res", [
+    (1024, 512, 512, 0, False), (2048, 2048, 512, 0, True), (1024, 512, 2048, 1, False), (512, 256, 768, 0, True),
+    (300, 256, 256, 1, True), (8192, 1024, 1024, 0, False), (1000, 4096, 1024, 0, True),
+])
+def test_linear_256_tile_kernel_matches_torch(M, K, N, act, res):
+    """shapes that the dispatcher sends to gemm256_bf16_kernel (LDS-DMA ring, 256 x 256 block tile)"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(M + 3 * K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    xb, wb = _bf(x), _bf(w)
+    ref = F.linear(xb.float(), wb.float(), b)
+    if act:
+        ref = F.gelu(ref)
+    if res:
+        ref = _bf(ref).float() + _bf(r).float()
+    for _ in range(3):  # the ring has no per-call state: repeated launches agree bit for bit
+        y = ops.linear(xb.to(DEV), wb.to(DEV), b.to(DEV), act=act, residual=None if r is None else _bf(r).to(DEV))
+        if _ == 0:
+            first = y.clone()
+        assert torch.equal(y, first)
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err
+
+
 def test_linear_rejects_bad_shapes():
     from flairhip import ops
     from flairhip.lib import FlairHipError
