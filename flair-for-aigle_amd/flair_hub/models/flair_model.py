@@ -290,6 +290,9 @@ class FLAIR_HUB_Model(nn.Module):
             return hnn.logits_view(y, len(self.config["labels_configs"][task]["value_name"]))
 
         def head1x1(conv, scores, task):  # the Sentinel-only model's nn.Conv2d(task_nclasses, classes, 1) (:153-166)
+            if self.training and torch.is_grad_enabled():
+                return hnn.logits_view(hnn.conv_bias(scores, conv),
+                                       len(self.config["labels_configs"][task]["value_name"]))
             pw = conv.packed(scores.dtype, ring=False)
             bias = torch.zeros(conv.out_pitch, dtype=torch.float32, device=scores.device)
             bias[: conv.out_channels] = conv.bias.detach()

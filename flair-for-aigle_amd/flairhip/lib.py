@@ -98,6 +98,13 @@ SIGNATURES = {
     "ffa_gelu": (_i, [_i, _p, _p, _ll, _p]),
     "ffa_adaptive_avg_pool": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ffa_bilinear_slice": (_i, [_i, _p, _p, _p] + [_i] * 9 + [_p]),
+    "ffa_reflect_pad1_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _p]),
+    "ffa_group_norm_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _ll, _i, _ll, _i, _i, _f, _i, _p]),
+    "ffa_ltae_attention_train": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "ffa_ltae_attention_bwd_blocks": (_i, [_i, _i, _i]),
+    "ffa_ltae_attention_bwd": (_i, [_i] + [_p] * 11 + [_i] * 6 + [_p]),
+    "ffa_temporal_aggregate_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "ffa_mul": (_i, [_i, _p, _p, _p, _ll, _p]),
     "ffa_bn_workspace_bytes": (_ll, [_i]),
     "ffa_bn_stats": (_i, [_i, _p, _ll, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _ll, _p]),
     "ffa_bn_finalize": (_i, [_p, _ll, _ll, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _ll, _p]),

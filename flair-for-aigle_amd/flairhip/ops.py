@@ -1160,3 +1160,96 @@ def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, out: Optional[torch.Tensor] 
     _l.check(lib.ffa_linear_wgrad(_dt(x), x.data_ptr(), K, dy.data_ptr(), N, out.data_ptr(), _ptr(db), M, K, N,
                                   1 if accumulate else 0, ws.data_ptr(), ws.numel(), _stream()), "linear_wgrad")
     return (out, db) if with_bias else out
+
+
+# --------------------------------------------------------------------------------------------------
+# U-TAE training (backward kernels of csrc/temporal.hip)
+
+def reflect_pad1_bwd(dpad: torch.Tensor) -> torch.Tensor:
+    _chk_nhwc(dpad, "reflect_pad1_bwd input")
+    N, Hp, Wp, C = dpad.shape
+    dx = torch.empty((N, Hp - 2, Wp - 2, C), dtype=dpad.dtype, device=dpad.device)
+    _l.check(_l.load().ffa_reflect_pad1_bwd(_dt(dpad), dpad.data_ptr(), dx.data_ptr(), N, Hp - 2, Wp - 2, C, _stream()),
+             "reflect_pad1_bwd")
+    return dx
+
+
+def _group_norm_bwd(x, dy, gamma, beta, groups, relu, geom, samples, eps):
+    lib = _l.load()
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    partial = torch.empty((samples, 2 * C), dtype=torch.float32, device=x.device)
+    Q, stride_hi, stride_lo, inner, inner_stride = geom
+    _l.check(lib.ffa_group_norm_bwd(_dt(x), x.data_ptr(), dy.data_ptr(), dx.data_ptr(), gamma.data_ptr(),
+                                    beta.data_ptr(), partial.data_ptr(), samples, Q, stride_hi, stride_lo, inner,
+                                    inner_stride, C, groups, eps, 1 if relu else 0, _stream()), "group_norm_bwd")
+    sums = column_sums(partial)
+    return dx, sums[:C].clone(), sums[C:].clone()
+
+
+def group_norm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int,
+                   relu: bool = False, eps: float = 1e-5):
+    """backward of group_norm (per image): -> (dx, dgamma, dbeta); a residual's gradient is dy itself"""
+    N, H, W, C = x.shape
+    return _group_norm_bwd(x, dy.contiguous(), gamma, beta, groups, relu, (1, H * W * C, 0, H * W, C), N, eps)
+
+
+def group_norm_seq_bwd(x: torch.Tensor, dy: torch.Tensor, B: int, T: int, gamma: torch.Tensor, beta: torch.Tensor,
+                       groups: int, eps: float = 1e-5):
+    """backward of group_norm_seq (per pixel over the T dates)"""
+    N, h, w, C = x.shape
+    P = h * w
+    return _group_norm_bwd(x, dy.contiguous(), gamma, beta, groups, False, (P, T * P * C, C, T, P * C), B * P, eps)
+
+
+def ltae_attention_train(k: torch.Tensor, v: torch.Tensor, Q: torch.Tensor, pad: torch.Tensor, B: int, T: int,
+                         drop: Optional[torch.Tensor] = None):
+    """-> (out [B,h,w,n_head*d_v], attn f32 [n_head,B,T,h*w] after the attention dropout, prob: the clean softmax)"""
+    _chk_nhwc(k, "ltae keys")
+    _chk_nhwc(v, "ltae values")
+    N, h, w, KC = k.shape
+    n_head, d_k = Q.shape
+    d_v = v.shape[-1] // n_head
+    out = torch.empty((B, h, w, n_head * d_v), dtype=v.dtype, device=v.device)
+    attn = torch.empty((n_head, B, T, h * w), dtype=torch.float32, device=v.device)
+    prob = torch.empty_like(attn)
+    _l.check(_l.load().ffa_ltae_attention_train(_dt(v), k.data_ptr(), v.data_ptr(), Q.data_ptr(), pad.data_ptr(),
+                                                _ptr(drop), out.data_ptr(), attn.data_ptr(), prob.data_ptr(), B, T,
+                                                h * w, n_head, d_k, d_v, _stream()), "ltae_attention_train")
+    return out, attn, prob
+
+
+def ltae_attention_bwd(k, v, Q, pad, drop, prob, dout, dattn_ext, B: int, T: int):
+    """-> (dk, dv, dQ f32 [n_head, d_k])"""
+    lib = _l.load()
+    N, h, w, KC = k.shape
+    n_head, d_k = Q.shape
+    d_v = v.shape[-1] // n_head
+    dk, dv = torch.empty_like(k), torch.empty_like(v)
+    nblk = lib.ffa_ltae_attention_bwd_blocks(B, h * w, n_head)
+    part = torch.empty((nblk, n_head * d_k), dtype=torch.float32, device=k.device)
+    _l.check(lib.ffa_ltae_attention_bwd(_dt(v), k.data_ptr(), v.data_ptr(), Q.data_ptr(), pad.data_ptr(), _ptr(drop),
+                                        prob.data_ptr(), dout.data_ptr(), _ptr(dattn_ext), dk.data_ptr(), dv.data_ptr(),
+                                        part.data_ptr(), B, T, h * w, n_head, d_k, d_v, _stream()), "ltae_attention_bwd")
+    dq = column_sums(part).view(n_head, d_k)
+    return dk, dv, dq
+
+
+def temporal_aggregate_bwd(x: torch.Tensor, attn: torch.Tensor, pad: torch.Tensor, dout: torch.Tensor, B: int, T: int,
+                           use_pad: bool):
+    """-> (dx like x, dattn f32 like attn)"""
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    dattn = torch.empty_like(attn)
+    _l.check(_l.load().ffa_temporal_aggregate_bwd(_dt(x), x.data_ptr(), attn.data_ptr(), pad.data_ptr(), dout.data_ptr(),
+                                                  dx.data_ptr(), dattn.data_ptr(), B, T, H * W, C, attn.shape[0],
+                                                  1 if use_pad else 0, _stream()), "temporal_aggregate_bwd")
+    return dx, dattn
+
+
+def mul(x: torch.Tensor, m: torch.Tensor) -> torch.Tensor:
+    if x.shape != m.shape or x.dtype != m.dtype or not x.is_contiguous() or not m.is_contiguous():
+        raise ValueError("mul: operands must be contiguous tensors of one shape and dtype")
+    y = torch.empty_like(x)
+    _l.check(_l.load().ffa_mul(_dt(x), x.data_ptr(), m.data_ptr(), y.data_ptr(), x.numel(), _stream()), "mul")
+    return y

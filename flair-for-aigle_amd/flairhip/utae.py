@@ -8,9 +8,10 @@ the conv epilogue; GroupNorm / attention / aggregation are the kernels of csrc/t
 BatchNorm is folded into the packed conv operand (scale) and its bias (shift), as everywhere else in the product.
 
 Scope: the stride-1 configuration FLAIR hard-codes (flair_zonal_detection/model_utils.py:55-71:
-str_conv k=3, s=1, p=1, agg_mode 'att_group', encoder_norm 'group', padding_mode 'reflect'); evaluation mode only --
-training this branch needs the backward kernels of GroupNorm / attention / aggregation, which do not exist yet, and
-raises NotImplementedError instead of falling back to torch.
+str_conv k=3, s=1, p=1, agg_mode 'att_group', encoder_norm 'group', padding_mode 'reflect').  Training runs through
+autograd nodes whose backward stays on the library (ffa_group_norm_bwd, ffa_reflect_pad1_bwd, ffa_ltae_attention_train /
+_bwd with the reference's attention dropout 0.1, ffa_temporal_aggregate_bwd, the conv dgrad / wgrad kernels, training-mode
+BatchNorm, nn.Dropout(0.2) after the L-TAE MLP as a mask multiply); there is no torch fallback.
 """
 from __future__ import annotations
 
@@ -70,6 +71,256 @@ def _block(**children) -> nn.Module:
     return m
 
 
+# --------------------------------------------------------------------------------------------------
+# training: autograd nodes
+
+def _wgrad_conv(x, dy, weight_shape, pad):
+    co, ci, kh, kw = weight_shape
+    return ops.conv_wgrad(x, dy, co, ci, kh, kw, 1, pad)
+
+
+def _bias_grad(d0, n):
+    return ops.column_sums(d0)[:n].clone()
+
+
+class _ConvGN(torch.autograd.Function):
+    """[residual +] relu(GroupNorm4(conv3x3_reflect(x) + bias)): ConvLayer with norm='group' (:452-497)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, residual, net, tag, holder):
+        xp = ops.reflect_pad1(x)
+        pw, bias = net._packed(tag, holder, x.shape[-1])
+        y0 = ops.conv2d(xp, pw, 0, ops.pad_channels(w.shape[0]), bias=bias)
+        g, be = gamma.detach().float(), beta.detach().float()
+        y = ops.group_norm(y0, g, be, 4, relu=True, residual=residual)
+        ctx.net, ctx.tag, ctx.holder, ctx.has_res = net, tag, holder, residual is not None
+        ctx.save_for_backward(xp, y0, g, be, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, y0, g, be, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        d0, dgam, dbet = ops.group_norm_bwd(y0, dy, g, be, 4, relu=True)
+        pwt, _ = ctx.net._packed(ctx.tag + ":T", ctx.holder, d0.shape[-1], transpose=True, with_bias=False)
+        dxp = ops.conv2d(d0, pwt, 2, xp.shape[-1], out_hw=(xp.shape[1], xp.shape[2]))
+        dx = ops.reflect_pad1_bwd(dxp) if ctx.needs_input_grad[0] else None
+        dw = _wgrad_conv(xp, d0, w.shape, 0)
+        db = _bias_grad(d0, w.shape[0])
+        return dx, dw, db, dgam, dbet, (dy if ctx.has_res else None), None, None, None
+
+
+class _ConvBN(torch.autograd.Function):
+    """relu(BatchNorm_train(conv(x) [+ conv_b(x2)] + bias)).  reflect: 3x3 with reflect padding (ConvLayer norm='batch');
+    otherwise a 1x1 convolution (skip_conv, the L-TAE MLP) or, with transpose, ConvTranspose2d(3, 1, 1) evaluated as a
+    convolution with the transposed operand.  The second source is the other half of a channel concat (UpConvBlock's
+    conv1 over cat([up, skip])): w's input-channel columns [0, c1) belong to x, the rest to x2."""
+
+    @staticmethod
+    def forward(ctx, x, x2, w, b, gamma, beta, net, tag, holder, bn, reflect, transpose, c1):
+        def prep(t):
+            return ops.reflect_pad1(t) if reflect else t
+        n_out = w.shape[1] if transpose else w.shape[0]
+        pitch = net._pitch(n_out)
+        pad = 1 if transpose else 0
+        xa = prep(x)
+        if x2 is None:
+            pw, bias = net._packed(tag, holder, x.shape[-1], transpose=transpose)
+            y0 = ops.conv2d(xa, pw, pad, pitch, bias=bias)
+            xb = None
+        else:
+            pa, bias = net._packed(tag + "a", holder, x.shape[-1], cols=slice(0, c1))
+            pb, _ = net._packed(tag + "b", holder, x2.shape[-1], cols=slice(c1, None), with_bias=False)
+            xb = prep(x2)
+            t = ops.conv2d(xa, pa, pad, pitch, bias=bias)
+            y0 = ops.conv2d(xb, pb, pad, pitch, residual=t)
+        ctx.c1 = c1
+        gam, bet = gamma.detach(), beta.detach()
+        if pitch != n_out:
+            # a class-score layer stored at the logits pitch: the statistics kernels work on the stored channels, so the
+            # affine parameters and running buffers are padded for the call (pad channels: gamma 0 -> output 0)
+            gam, bet = torch.zeros(pitch, device=x.device), torch.zeros(pitch, device=x.device)
+            gam[:n_out], bet[:n_out] = gamma.detach(), beta.detach()
+            rm, rv = torch.zeros(pitch, device=x.device), torch.ones(pitch, device=x.device)
+            rm[:n_out], rv[:n_out] = bn.running_mean, bn.running_var
+            scale, shift, mean, rstd = ops.bn_stats(y0, gam, bet, rm, rv, bn.momentum, bn.eps)
+            bn.running_mean.copy_(rm[:n_out])
+            bn.running_var.copy_(rv[:n_out])
+        else:
+            scale, shift, mean, rstd = ops.bn_stats(y0, gam, bet, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+        bn.note_batch()
+        y = ops.bn_apply(y0, scale, shift, relu=True)
+        ctx.net, ctx.tag, ctx.holder, ctx.flags = net, tag, holder, (reflect, transpose, x2 is not None)
+        ctx.n_out = n_out
+        ctx.save_for_backward(xa, xb, y0, gam, bet, mean, rstd, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, xb, y0, gamma, beta, mean, rstd, w = ctx.saved_tensors
+        reflect, transpose, two = ctx.flags
+        net, tag, holder = ctx.net, ctx.tag, ctx.holder
+        d0, _, dgam, dbet = ops.bn_bwd(y0, dy.contiguous(), None, gamma, beta, mean, rstd, True, False)
+        n_out = ctx.n_out
+        dgam, dbet = dgam[:n_out].clone(), dbet[:n_out].clone()
+        db = _bias_grad(d0, n_out)
+        k = w.shape[-1] if w.dim() == 4 else 1
+
+        def unprep(dxp):
+            return ops.reflect_pad1_bwd(dxp) if reflect else dxp
+
+        if transpose:
+            # y = C^T x with C the convolution whose OIHW weight is w [in, out, 3, 3]: dx = C dy, dW = wgrad(input dy, grad x)
+            pwd, _ = net._packed(tag + ":D", holder, d0.shape[-1], with_bias=False)
+            dx = ops.conv2d(d0, pwd, 1, xa.shape[-1]) if ctx.needs_input_grad[0] else None
+            dw = ops.conv_wgrad(d0, xa, w.shape[0], w.shape[1], 3, 3, 1, 1)
+            return dx, None, dw, db, dgam, dbet, None, None, None, None, None, None, None
+        w4 = w.shape if w.dim() == 4 else (w.shape[0], w.shape[1], 1, 1)
+        dpad = k - 1  # full correlation of the unpadded convolution (pad 0)
+        if not two:
+            pwt, _ = net._packed(tag + ":T", holder, d0.shape[-1], transpose=True, with_bias=False)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = unprep(ops.conv2d(d0, pwt, dpad, xa.shape[-1], out_hw=(xa.shape[1], xa.shape[2])))
+            dw = _wgrad_conv(xa, d0, w4, 0).view(w.shape)
+            return dx, None, dw, db, dgam, dbet, None, None, None, None, None, None, None
+        c1 = ctx.c1
+        pat, _ = net._packed(tag + "a:T", holder, d0.shape[-1], transpose=True, with_bias=False, cols=slice(0, c1))
+        pbt, _ = net._packed(tag + "b:T", holder, d0.shape[-1], transpose=True, with_bias=False, cols=slice(c1, None))
+        dx = unprep(ops.conv2d(d0, pat, dpad, xa.shape[-1], out_hw=(xa.shape[1], xa.shape[2])))
+        dx2 = unprep(ops.conv2d(d0, pbt, dpad, xb.shape[-1], out_hw=(xb.shape[1], xb.shape[2])))
+        dwa = _wgrad_conv(xa, d0, (w4[0], c1, k, k), 0)
+        dwb = _wgrad_conv(xb, d0, (w4[0], w4[1] - c1, k, k), 0)
+        dw = torch.cat([dwa, dwb], dim=1).view(w.shape)
+        return dx, dx2, dw, db, dgam, dbet, None, None, None, None, None, None, None
+
+
+class _Conv1x1(torch.autograd.Function):
+    """x W^T + b for a Conv1d(k=1) / nn.Linear weight on NHWC tokens (LTAE2d.inconv, MultiHeadAttention.fc1_k)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, net, tag, holder):
+        pw, bias = net._packed(tag, holder, x.shape[-1])
+        n_out = w.shape[0]
+        y = ops.conv2d(x, pw, 0, ops.pad_channels(n_out), bias=bias)
+        ctx.net, ctx.tag, ctx.holder = net, tag, holder
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        pwt, _ = ctx.net._packed(ctx.tag + ":T", ctx.holder, dy.shape[-1], transpose=True, with_bias=False)
+        dx = ops.conv2d(dy, pwt, 0, x.shape[-1]) if ctx.needs_input_grad[0] else None
+        dw = ops.conv_wgrad(x, dy, w.shape[0], w.shape[1], 1, 1, 1, 0).view(w.shape)
+        return dx, dw, _bias_grad(dy, w.shape[0]), None, None, None
+
+
+class _GNSeq(torch.autograd.Function):
+    """GroupNorm over the dates of each pixel (LTAE2d.in_norm; out_norm with T = 1)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, B, T, groups):
+        g, be = gamma.detach().float(), beta.detach().float()
+        ctx.geom = (B, T, groups)
+        ctx.save_for_backward(x, g, be)
+        return ops.group_norm_seq(x, B, T, g, be, groups)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, be = ctx.saved_tensors
+        B, T, groups = ctx.geom
+        dx, dg, db = ops.group_norm_seq_bwd(x, dy, B, T, g, be, groups)
+        return dx, dg, db, None, None, None
+
+
+class _MaskImages(torch.autograd.Function):
+    """TemporallySharedBlock.smart_forward: padded dates come out as pad_value and pass no gradient"""
+
+    @staticmethod
+    def forward(ctx, x, pad, value):
+        ctx.save_for_backward(pad)
+        return ops.mask_images_(x.clone(), pad, value)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (pad,) = ctx.saved_tensors
+        return ops.mask_images_(dy.clone(), pad, 0.0), None, None
+
+
+class _AddRows(torch.autograd.Function):
+    """z + positional encoding (f32 [n, C], no gradient)"""
+
+    @staticmethod
+    def forward(ctx, z, pe):
+        return ops.add_rowvec_(z.clone(), pe)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None
+
+
+class _LtaeAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, keys, values, Q, pad, B, T, drop):
+        q = Q.detach().float().contiguous()
+        out, attn, prob = ops.ltae_attention_train(keys, values, q, pad, B, T, drop)
+        ctx.geom = (B, T)
+        ctx.save_for_backward(keys, values, q, pad, drop, prob)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, dout, dattn):
+        keys, values, q, pad, drop, prob = ctx.saved_tensors
+        B, T = ctx.geom
+        dattn = None if dattn is None else dattn.contiguous()
+        dk, dv, dq = ops.ltae_attention_bwd(keys, values, q, pad, drop, prob, dout.contiguous(), dattn, B, T)
+        return dk, dv, dq, None, None, None, None
+
+
+class _Aggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, attn, pad, B, T, use_pad):
+        ctx.geom = (B, T, use_pad)
+        ctx.save_for_backward(x, attn, pad)
+        return ops.temporal_aggregate(x, attn, pad, B, T, use_pad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, attn, pad = ctx.saved_tensors
+        B, T, use_pad = ctx.geom
+        dx, dattn = ops.temporal_aggregate_bwd(x, attn, pad, dy.contiguous(), B, T, use_pad)
+        return dx, dattn, None, None, None, None
+
+
+class _Mul(torch.autograd.Function):
+    """x * mask (nn.Dropout with a pre-scaled keep mask)"""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return ops.mul(x, mask)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        return ops.mul(dy.contiguous(), mask), None
+
+
+class _Add(torch.autograd.Function):
+    """a + b through ffa_bn_apply's residual input ("out + conv2(out)" of UpConvBlock :598)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        one = torch.ones(a.shape[-1], dtype=torch.float32, device=a.device)
+        return ops.bn_apply(a, one, torch.zeros_like(one), residual=b, relu=False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
 class HipUTAE(nn.Module):
     def __init__(self, input_dim: int, encoder_widths=(64, 64, 64, 128), decoder_widths=(32, 32, 64, 128),
                  out_conv=(32, 20), str_conv_k: int = 4, str_conv_s: int = 2, str_conv_p: int = 1,
@@ -115,6 +366,9 @@ class HipUTAE(nn.Module):
         self.temporal_encoder = te
         self.out_conv = _block(conv=_conv_layer([dec[0]] + list(out_conv), "batch"))
         self._cache = {}
+        # training-time randomness of the reference: LTAE2d(dropout=0.2) after its MLP (:242,278),
+        # ScaledDotProductAttention(attn_dropout=0.1) on the temporal attention masks (:387,399)
+        self.mlp_dropout, self.attn_dropout = 0.2, 0.1
 
     # ---- operand preparation (cached per parameter version) ----------------------------------------
 
@@ -175,9 +429,11 @@ class HipUTAE(nn.Module):
     def forward_nhwc(self, x: torch.Tensor, batch_positions: torch.Tensor):
         """x f32 [B,T,C,H,W], batch_positions [B,T] -> (logits NHWC [B,H,W,pitch], maps NHWC (coarse to fine),
         attn f32 [n_head,B,T,H,W])"""
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(x, batch_positions)
         if self.training:
-            raise NotImplementedError("HipUTAE: evaluation-mode forward only (no backward kernels for GroupNorm / "
-                                      "L-TAE attention / temporal aggregation yet); call .eval()")
+            raise NotImplementedError("HipUTAE in training mode runs under autograd only (BatchNorm batch statistics "
+                                      "and dropout belong to the training step); call .eval() for inference")
         if not x.is_cuda:
             raise RuntimeError("HipUTAE runs on the MI355X only (no CPU path in the product)")
         B, T, C, H, W = x.shape
@@ -243,6 +499,76 @@ class HipUTAE(nn.Module):
         logits = out
         for j in range(len(seq) // 3):
             logits = self._conv_bn(logits, seq, 3 * j, f"o{j}")
+        return logits, maps, attn.view(self.n_head, B, T, H, W)
+
+    def _forward_train(self, x: torch.Tensor, batch_positions: torch.Tensor):
+        """training-mode forward_nhwc through autograd nodes (same return convention)"""
+        if not x.is_cuda:
+            raise RuntimeError("HipUTAE runs on the MI355X only (no CPU path in the product)")
+        B, T, C, H, W = x.shape
+        if C != self.input_dim or H < 2 or W < 2:
+            raise ValueError(f"expected [B,T,{self.input_dim},H>=2,W>=2], got {tuple(x.shape)}")
+        N = B * T
+        flat = x.reshape(N, C, H, W).float().contiguous()
+        pad = ops.detect_pad_images(flat, self.pad_value)
+        any_pad = bool(pad.any())
+        cur = ops.nchw_to_nhwc(flat, self.dtype, ops.pad_channels(C))
+
+        def gn(t, seq, idx, tag, residual=None):
+            conv, nrm = seq[idx], seq[idx + 1]
+            return _ConvGN.apply(t, conv.weight, conv.bias, nrm.weight, nrm.bias, residual, self, tag, conv)
+
+        def bnc(t, conv, bn, tag, reflect=True, transpose=False, t2=None, c1=0):
+            return _ConvBN.apply(t, t2, conv.weight, conv.bias, bn.weight, bn.bias, self, tag, conv, bn, reflect,
+                                 transpose, c1)
+
+        def shared(t):
+            return _MaskImages.apply(t, pad, self.pad_value)
+
+        seq = self.in_conv.conv.conv
+        cur = shared(gn(gn(cur, seq, 0, "in0"), seq, 3, "in1"))
+        fmaps: List[torch.Tensor] = [cur]
+        for i, blk in enumerate(self.down_blocks):
+            t = gn(fmaps[-1], blk.down.conv, 0, f"d{i}a")
+            t = gn(t, blk.conv1.conv, 0, f"d{i}b")
+            t = gn(t, blk.conv2.conv, 0, f"d{i}c", residual=t)
+            fmaps.append(shared(t))
+
+        te = self.temporal_encoder
+        z = _GNSeq.apply(fmaps[-1], te.in_norm.weight, te.in_norm.bias, B, T, self.n_head)
+        z = _Conv1x1.apply(z, te.inconv.weight, te.inconv.bias, self, "inconv", te.inconv)
+        pe = ops.positional_encoding(batch_positions.to(x.device), self.d_model // self.n_head, self.n_head)
+        z = _AddRows.apply(z, pe)
+        fk = te.attention_heads.fc1_k
+        keys = _Conv1x1.apply(z, fk.weight, fk.bias, self, "fc1_k", fk)
+        drop = None
+        if self.attn_dropout > 0:
+            keep = 1.0 - self.attn_dropout
+            drop = torch.empty((self.n_head, B, T, H * W), dtype=torch.float32, device=x.device).bernoulli_(keep).div_(keep)
+        o, attn = _LtaeAttention.apply(keys, z, te.attention_heads.Q, pad, B, T, drop)
+        o = bnc(o, te.mlp[0], te.mlp[1], "mlp", reflect=False)
+        if self.mlp_dropout > 0:
+            keep = 1.0 - self.mlp_dropout
+            o = _Mul.apply(o, torch.empty_like(o).bernoulli_(keep).div_(keep))
+        out = _GNSeq.apply(o, te.out_norm.weight, te.out_norm.bias, B, 1, self.n_head)
+
+        maps = [out]
+        for i, blk in enumerate(self.up_blocks):
+            skip_src = fmaps[-(i + 2)]
+            if skip_src.shape[1:3] != fmaps[-1].shape[1:3]:
+                raise NotImplementedError("attention masks are used at their own resolution (stride-1 U-TAE)")
+            skip = _Aggregate.apply(skip_src, attn, pad, B, T, any_pad)
+            d_out = blk.up[0].weight.shape[1]
+            up = bnc(out, blk.up[0], blk.up[1], f"u{i}up", reflect=False, transpose=True)
+            sk = bnc(skip, blk.skip_conv[0], blk.skip_conv[1], f"u{i}skip", reflect=False)
+            y = bnc(up, blk.conv1.conv[0], blk.conv1.conv[1], f"u{i}c1", t2=sk, c1=d_out)
+            y2 = bnc(y, blk.conv2.conv[0], blk.conv2.conv[1], f"u{i}c2")
+            out = _Add.apply(y2, y)
+            maps.append(out)
+        seq = self.out_conv.conv.conv
+        logits = out
+        for j in range(len(seq) // 3):
+            logits = bnc(logits, seq[3 * j], seq[3 * j + 1], f"o{j}")
         return logits, maps, attn.view(self.n_head, B, T, H, W)
 
     def forward(self, input: torch.Tensor, batch_positions: Optional[torch.Tensor] = None, return_att: bool = False):

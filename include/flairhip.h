@@ -166,6 +166,30 @@ int ffa_detect_pad_images(const float* x, unsigned char* pad, int N, long long p
                           ffa_stream_t stream);
 int ffa_mask_images(int dtype, void* x, const unsigned char* pad, int N, long long per_image, float value,
                     ffa_stream_t stream);
+/* -- training of the branch: backward of the pieces above (autograd of multitemp_model.py's modules) -- */
+int ffa_reflect_pad1_bwd(int dtype, const void* dpad, void* dx, int N, int H, int W, int C, ffa_stream_t stream);
+/* GroupNorm backward, ffa_group_norm's geometry; y = [res +] relu?(GN(x)): the residual's gradient is dy itself.
+ * partial f32 [samples][2][C] receives per-sample (sum dy' xhat, sum dy'): the caller sums the rows (ffa_column_sums) */
+int ffa_group_norm_bwd(int dtype, const void* x, const void* dy, void* dx, const float* gamma, const float* beta,
+                       float* partial, long long samples, int Q, long long stride_hi, long long stride_lo, int inner,
+                       long long inner_stride, int C, int groups, float eps, int relu, ffa_stream_t stream);
+/* ffa_ltae_attention with the attention dropout of ScaledDotProductAttention (:399): drop f32 [n_head][B][T][P] = 0 or
+ * 1 / (1 - p) (nullable); attn = the dropped-out masks (what the reference returns), prob = the clean softmax (kept) */
+int ffa_ltae_attention_train(int dtype, const void* k, const void* v, const float* Q, const unsigned char* pad,
+                             const float* drop, void* out, float* attn, float* prob, int B, int T, int P, int n_head,
+                             int d_k, int d_v, ffa_stream_t stream);
+/* its backward: dout [B][P][n_head*d_v], dattn_ext f32 [n_head][B][T][P] (nullable: gradient the aggregators send to the
+ * returned masks) -> dk, dv (layouts of k, v) and dq_partial f32 [ffa_ltae_attention_bwd_blocks()][n_head*d_k] (rows to sum) */
+int ffa_ltae_attention_bwd_blocks(int B, int P, int n_head);
+int ffa_ltae_attention_bwd(int dtype, const void* k, const void* v, const float* Q, const unsigned char* pad,
+                           const float* drop, const float* prob, const void* dout, const float* dattn_ext, void* dk,
+                           void* dv, float* dq_partial, int B, int T, int P, int n_head, int d_k, int d_v,
+                           ffa_stream_t stream);
+int ffa_temporal_aggregate_bwd(int dtype, const void* x, const float* attn, const unsigned char* pad, const void* dout,
+                               void* dx, float* dattn, int B, int T, int P, int C, int n_head, int use_pad,
+                               ffa_stream_t stream);
+/* y = x * m elementwise (nn.Dropout with a pre-scaled keep mask; its own backward) */
+int ffa_mul(int dtype, const void* x, const void* m, void* y, long long n, ffa_stream_t stream);
 
 /* ---- Swin-Transformer encoder + UPerNet decoder (the reference's default `swin_*-upernet` architecture:
  *      configs/train/config_models.yaml:5, configs/config_model_zonal_segmentation.yaml:26, resolved through

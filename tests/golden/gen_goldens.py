@@ -462,6 +462,36 @@ def gen_sentinel(path_json, path_npz):
                                         if k.startswith(("encoders.SENTINEL2_TS", "fusion_handler"))},
                   "multitemp_model": {k: cfg["models"]["multitemp_model"][k] for k in ("encoder_widths", "decoder_widths", "out_conv")}}
     print("  sentinel s2:", {k: tuple(v.shape) for k, v in lt.items()}, info["s2"]["multitemp_model"])
+    # ---- s2 training step: aerial U-Net + Sentinel branch fused per stage, SegmentationTask.step + backward with the two
+    # nn.Dropout probabilities of the U-TAE set to 0 on the instance (deterministic step) ----
+    g2 = torch.Generator().manual_seed(47)
+    task.model.load_state_dict(_fill_mixed(task.model.state_dict()))
+    te = task.model.encoders["SENTINEL2_TS"].temporal_encoder
+    te.dropout.p = 0.0
+    te.attention_heads.attention.dropout.p = 0.0
+    xa = torch.randn(3, 5, 64, 64, generator=g2)
+    xs = torch.randn(3, 4, 10, 10, 10, generator=g2)
+    xs[2, 3] = 0.0
+    pos = torch.sort(torch.randint(0, 365, (3, 4), generator=g2), dim=1).values.float()
+    tc = torch.randint(0, 19, (3, 64, 64), generator=g2)
+    batch = {"AERIAL_RGBI": xa, "SENTINEL2_TS": xs, "SENTINEL2_DATES": pos,
+             "AERIAL_LABEL-COSIA": torch.nn.functional.one_hot(tc, 19).permute(0, 3, 1, 2).float()}
+    task.train()
+    loss, preds, _ = task.step(batch, training=True)
+    loss.backward()
+    named = dict(task.model.named_parameters())
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in named.values() if p.grad is not None))
+    sampled = ["encoders.SENTINEL2_TS.in_conv.conv.conv.0.weight", "encoders.SENTINEL2_TS.temporal_encoder.attention_heads.Q",
+               "encoders.SENTINEL2_TS.temporal_encoder.inconv.weight", "encoders.SENTINEL2_TS.up_blocks.0.up.0.weight",
+               "encoders.SENTINEL2_TS.down_blocks.2.conv2.conv.1.weight", "fusion_handler.conv_f.3.weight",
+               "encoders.AERIAL_RGBI.seg_model.layer1.0.conv1.weight"]
+    out.update(s2t_x_aerial=xa.numpy(), s2t_x=xs.numpy(), s2t_pos=pos.numpy(), s2t_target=tc.numpy().astype(np.uint8),
+               **{"s2t_grad__" + k: named[k].grad.numpy() for k in sampled})
+    info["s2_train"] = {"loss": hexf(loss.item()), "grad_norm": float(gn),
+                        "grad_norms": {k: float(p.grad.double().norm()) for k, p in named.items() if p.grad is not None},
+                        "unused_parameters": sorted(k for k, p in named.items() if p.grad is None)}
+    print(f"  sentinel s2 train: loss {loss.item():.6f} grad-norm {float(gn):.6f}, "
+          f"{len(info['s2_train']['unused_parameters'])} parameters without gradient")
     np.savez_compressed(path_npz, **out)
     json.dump(info, open(path_json, "w"), indent=1)
 

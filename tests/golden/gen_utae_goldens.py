@@ -56,6 +56,44 @@ def main():
               float(logits.abs().max()), float(logits.std()))
     np.savez_compressed(os.path.join(HERE, "utae_eval.npz"), **out)
     print("keys:", len(net.state_dict()), "params:", sum(p.numel() for p in net.parameters()))
+    gen_training(net)
+
+
+def gen_training(net):
+    """tests/golden/utae_train.npz: one training-mode forward + backward of the reference's UTAE (BatchNorm batch
+    statistics; the two nn.Dropout probabilities set to 0 on the INSTANCE so that the step is deterministic; padded dates
+    present) -- loss, class scores, and for every parameter the gradient's norm plus the whole gradient (small tensors) or
+    a strided sample of it."""
+    net.load_state_dict(fill_utae_state_dict(net.state_dict()))
+    net.train()
+    net.temporal_encoder.dropout.p = 0.0
+    net.temporal_encoder.attention_heads.attention.dropout.p = 0.0
+    g = torch.Generator().manual_seed(21)
+    B, T, H, W = 3, 5, 10, 10
+    x = torch.randn(B, T, 10, H, W, generator=g)
+    for b, t in [(0, 4), (2, 3), (2, 4)]:
+        x[b, t] = 0.0
+    pos = torch.sort(torch.randint(0, 365, (B, T), generator=g), dim=1).values.float()
+    tgt = torch.randint(0, 19, (B, H, W), generator=g)
+    for p in net.parameters():
+        p.grad = None
+    logits, maps = net(x, batch_positions=pos)
+    loss = torch.nn.functional.cross_entropy(logits, tgt)
+    loss.backward()
+    out = {"x": x.numpy(), "pos": pos.numpy(), "target": tgt.numpy().astype(np.uint8), "logits": logits.detach().numpy(),
+           "loss": np.float64(loss.item())}
+    names = []
+    for k, p in net.named_parameters():
+        gr = p.grad.detach().flatten()
+        names.append(k)
+        out["norm__" + k] = np.float64(gr.double().norm().item())
+        out["grad__" + k] = (gr if gr.numel() <= 4096 else gr[:: max(1, gr.numel() // 2048)]).numpy()
+    # BatchNorm running statistics after the step (momentum update of the batch statistics)
+    for k, v in net.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            out["stat__" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "utae_train.npz"), **out)
+    print("train: loss", loss.item(), "params", len(names), "fixture keys", len(out))
 
 
 if __name__ == "__main__":

@@ -79,3 +79,42 @@ def test_aerial_plus_sentinel_fusion_matches_the_reference(cuda):
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
     assert (got.argmax(1) == ref.argmax(1)).mean() >= 0.999
+
+
+def test_aerial_plus_sentinel_training_step_matches_the_reference(cuda):
+    """sentinel.{npz,json} s2_train: the reference's own SegmentationTask.step + backward on the aerial U-Net fused per
+    stage with the U-TAE branch (BatchNorm batch statistics, a padded date, U-TAE dropouts at p = 0): loss, total and
+    per-parameter gradient norms, sampled gradients, the set of parameters without gradient"""
+    import torch.nn.functional as F
+    from flairhip.configs import unet_resnet34_config
+    from flair_hub.tasks.module_setup import build_segmentation_module
+    d = np.load(os.path.join(GOLD, "sentinel.npz"))
+    info = json.load(open(os.path.join(GOLD, "sentinel.json")))["s2_train"]
+    cfg = unet_resnet34_config(in_channels=5, precision="fp32")
+    cfg["modalities"]["inputs"]["SENTINEL2_TS"] = True
+    cfg["modalities"]["inputs_channels"]["SENTINEL2_TS"] = list(range(1, 11))
+    task = build_segmentation_module(cfg, {"AERIAL_RGBI": 64, "SENTINEL2_TS": 10}, "train")
+    task.model.load_state_dict(_fill(task.model.state_dict()))
+    task = task.to(cuda).train()
+    utae = task.model.encoders["SENTINEL2_TS"]
+    utae.mlp_dropout = utae.attn_dropout = 0.0
+    tc = torch.tensor(d["s2t_target"]).long()
+    batch = {"AERIAL_RGBI": torch.tensor(d["s2t_x_aerial"]).to(cuda), "SENTINEL2_TS": torch.tensor(d["s2t_x"]).to(cuda),
+             "SENTINEL2_DATES": torch.tensor(d["s2t_pos"]).to(cuda),
+             "AERIAL_LABEL-COSIA": F.one_hot(tc, 19).permute(0, 3, 1, 2).float().contiguous().to(cuda)}
+    loss, preds, _ = task.step(batch, training=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_loss = float.fromhex(info["loss"])
+    assert abs(loss.item() - ref_loss) <= 5e-5 * ref_loss
+    named = dict(task.model.named_parameters())
+    assert sorted(k for k, p in named.items() if p.grad is None) == info["unused_parameters"]
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in named.values() if p.grad is not None)).item()
+    assert abs(gn - info["grad_norm"]) <= 1e-2 * info["grad_norm"]
+    off = [(k, n, named[k].grad.double().norm().item()) for k, n in info["grad_norms"].items()
+           if n > 1e-6 and abs(named[k].grad.double().norm().item() - n) > 5e-2 * n]
+    assert not off, off[:8]
+    for k in [f[len("s2t_grad__"):] for f in d.files if f.startswith("s2t_grad__")]:
+        ref = d["s2t_grad__" + k]
+        rel = np.linalg.norm(named[k].grad.cpu().numpy() - ref) / np.linalg.norm(ref)
+        assert rel <= 2e-2, f"{k}: relative gradient error {rel}"

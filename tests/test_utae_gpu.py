@@ -79,7 +79,7 @@ def test_utae_refuses_what_it_does_not_cover(cuda):
         HipUTAE(10)  # the original U-TAE defaults (strided 4/2/1 convolutions) are not FLAIR's configuration
     net, _ = _model(cuda, "fp32")
     net.train()
-    with pytest.raises(NotImplementedError):
+    with torch.no_grad(), pytest.raises(NotImplementedError):  # training mode outside a training step
         net(torch.randn(1, 2, 10, 8, 8, device=cuda), batch_positions=torch.zeros(1, 2, device=cuda))
 
 
@@ -110,3 +110,68 @@ def test_group_norm_and_reflect_pad_kernels(cuda, dtype):
     seq = sq.permute(0, 3, 4, 2, 1).reshape(B * h * w, C2, T)  # [pixels, C, T] as LTAE2d builds it
     ref = F.group_norm(seq, 16, g2, b2, 1e-5).reshape(B, h, w, C2, T).permute(0, 4, 1, 2, 3).reshape(B * T, h, w, C2)
     assert (got.float().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_utae_training_step_matches_the_references_own_autograd(cuda, precision):
+    """tests/golden/utae_train.npz: training-mode forward + backward of the REFERENCE'S OWN UTAE (BatchNorm batch
+    statistics, padded dates, both dropouts at p = 0): loss, class scores, every parameter gradient (norm + values) and
+    the BatchNorm running statistics after the step"""
+    from flairhip import nn as hnn
+    net, _ = _model(cuda, precision)
+    net.train()
+    net.mlp_dropout = net.attn_dropout = 0.0
+    d = np.load(os.path.join(GOLD, "utae_train.npz"))
+    x, pos = torch.tensor(d["x"]).to(cuda), torch.tensor(d["pos"]).to(cuda)
+    tgt = torch.tensor(d["target"]).to(cuda)
+    logits_nhwc, maps, attn = net.forward_nhwc(x, pos)
+    logits = hnn.logits_view(logits_nhwc, 19)
+    crit = hnn.HipCrossEntropyLoss(num_classes=19).to(cuda)
+    loss = crit(logits, tgt)
+    loss.backward()
+    torch.cuda.synchronize()
+    f32 = precision == "fp32"
+    ref_logits = d["logits"]
+    got = logits.detach().float().cpu().numpy()
+    assert np.abs(got - ref_logits).max() <= (2e-4 if f32 else 0.12) * max(1.0, np.abs(ref_logits).max())
+    assert abs(loss.item() - float(d["loss"])) <= (1e-4 if f32 else 2e-2) * float(d["loss"])
+    bad, coss = [], []
+    for k, p in net.named_parameters():
+        assert p.grad is not None, k
+        g = p.grad.detach().float().cpu().flatten()
+        ref_norm = float(d["norm__" + k])
+        ref = torch.tensor(d["grad__" + k])
+        sample = g if g.numel() <= 4096 else g[:: max(1, g.numel() // 2048)]
+        assert sample.shape == ref.shape, k
+        if ref_norm < 1e-7:  # biases in front of a training-mode BatchNorm: exact zero in exact arithmetic
+            assert g.norm().item() <= (1e-4 if f32 else 2e-2), k
+            continue
+        ratio = g.double().norm().item() / ref_norm
+        cos = F.cosine_similarity(sample, ref, dim=0).item() if ref.norm() > 0 else 1.0
+        lim_r, lim_c = ((0.98, 1.02), 0.999) if f32 else ((0.7, 1.4), 0.6)  # bf16 storage through ~20 GroupNorm layers on 10 x 10 maps; fp32 pins the arithmetic
+        coss.append(cos)
+        if not (lim_r[0] <= ratio <= lim_r[1]) or cos < lim_c:
+            bad.append((k, round(ratio, 4), round(cos, 4)))
+    assert not bad, bad[:10]
+    assert sum(coss) / len(coss) >= (0.9995 if f32 else 0.8)
+    sd = net.state_dict()
+    for k in d.files:
+        if k.startswith("stat__"):
+            ref = d[k]
+            got = sd[k[len("stat__"):]].float().cpu().numpy()
+            assert np.abs(got - ref).max() <= (1e-4 if f32 else 5e-2) * max(1.0, np.abs(ref).max()), k
+
+
+def test_utae_dropout_and_no_grad_behaviour(cuda):
+    net, _ = _model(cuda, "bf16")
+    net.train()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 4, 10, 8, 8, generator=g).to(cuda)
+    pos = torch.tensor([[1.0, 40.0, 90.0, 200.0]] * 2).to(cuda)
+    a = net.forward_nhwc(x, pos)[0]
+    b = net.forward_nhwc(x, pos)[0]
+    assert not torch.equal(a, b)  # the reference's two dropouts draw new masks per call
+    a.float().sum().backward()
+    assert all(p.grad is not None for p in net.parameters())
+    with torch.no_grad(), pytest.raises(NotImplementedError):
+        net.forward_nhwc(x, pos)  # training mode without autograd is neither a training step nor an evaluation
