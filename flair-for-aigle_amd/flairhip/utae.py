@@ -442,7 +442,9 @@ class HipUTAE(nn.Module):
         N = B * T
         flat = x.reshape(N, C, H, W).float().contiguous()
         pad = ops.detect_pad_images(flat, self.pad_value)            # u8 [N], n = b * T + t
-        any_pad = bool(pad.any())                                    # Temporal_Aggregator branches on it (:609)
+        # Temporal_Aggregator branches on pad_mask.any() (:609) only to skip a multiplication by (~pad_mask): applying the
+        # mask always is the same arithmetic and needs no device -> host synchronisation (the step stays graph-capturable)
+        any_pad = True
         cur = ops.nchw_to_nhwc(flat, self.dtype, ops.pad_channels(C))
 
         def shared(t):  # TemporallySharedBlock.smart_forward: padded dates come out as pad_value
@@ -511,7 +513,7 @@ class HipUTAE(nn.Module):
         N = B * T
         flat = x.reshape(N, C, H, W).float().contiguous()
         pad = ops.detect_pad_images(flat, self.pad_value)
-        any_pad = bool(pad.any())
+        any_pad = True  # see forward_nhwc: the mask is applied unconditionally (no host synchronisation)
         cur = ops.nchw_to_nhwc(flat, self.dtype, ops.pad_channels(C))
 
         def gn(t, seq, idx, tag, residual=None):

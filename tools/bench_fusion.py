@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--tile", type=int, default=512)
     ap.add_argument("--dem-tile", type=int, default=128)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--sentinel", type=int, default=0, metavar="T",
+                    help="add the Sentinel-2 time-series branch (U-TAE, T dates of 10 x 10 px x 10 bands): BASELINE configs[4]")
     args = ap.parse_args()
     from flairhip.configs import fusion_unet_config
     from flair_hub.tasks.module_setup import build_segmentation_module
@@ -39,8 +41,13 @@ def main():
     dev = torch.device("cuda:0")
     cfg = fusion_unet_config(precision="bf16", batch_size=args.batch)
     cfg["hyperparams"]["total_steps"] = args.steps + args.warmup + 32
+    sizes = {MOD: args.tile, DEM: args.dem_tile}
+    if args.sentinel:
+        cfg["modalities"]["inputs"]["SENTINEL2_TS"] = True
+        cfg["modalities"]["inputs_channels"]["SENTINEL2_TS"] = list(range(1, 11))
+        sizes["SENTINEL2_TS"] = 10
     torch.manual_seed(2025)
-    task = build_segmentation_module(cfg, {MOD: args.tile, DEM: args.dem_tile}, "train").to(dev)
+    task = build_segmentation_module(cfg, sizes, "train").to(dev)
     task.train()
     oc = task.configure_optimizers()
     optimizer, scheduler = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
@@ -50,6 +57,10 @@ def main():
              DEM: torch.randn(B, 2, D, D, generator=g, device=dev),
              COSIA: torch.randint(0, 19, (B, S, S), generator=g, device=dev, dtype=torch.uint8),
              LPIS: torch.randint(0, 23, (B, S, S), generator=g, device=dev, dtype=torch.uint8)}
+    if args.sentinel:
+        T = args.sentinel
+        batch["SENTINEL2_TS"] = torch.randn(B, T, 10, 10, 10, generator=g, device=dev)
+        batch["SENTINEL2_DATES"] = torch.sort(torch.randint(0, 365, (B, T), generator=g, device=dev), dim=1).values.float()
     nparams = sum(p.numel() for p in task.model.parameters())
 
     def eager_step(i):
@@ -77,8 +88,9 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({
-        "metric": "512x512x5 (+128x128x2 DEM) tiles/sec, two-encoder fused U-Net ResNet-34, COSIA + LPIS + aux decoder, "
-                  "train fwd+bwd+AdamW",
+        "metric": "512x512x5 (+128x128x2 DEM" + (f" + {args.sentinel} Sentinel-2 dates" if args.sentinel else "") +
+                  ") tiles/sec, two-encoder fused U-Net ResNet-34" + (" + U-TAE" if args.sentinel else "") +
+                  ", COSIA + LPIS + aux decoder, train fwd+bwd+AdamW",
         "value": round(B * args.steps / dt, 2), "unit": "tiles/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
         "batch": B, "steps": args.steps, "warmup": args.warmup, "dtype": "bf16", "hip_graph": graphed is not None,
         "parameters": nparams, "final_loss": round(float(loss.item()), 5),
