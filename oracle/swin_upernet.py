@@ -18,7 +18,13 @@ stages 1..3; smp 0.4.0 decoders/upernet/decoder.py + base/heads.py + encoders/ti
   * the "0-channel dummy feature at stride 2" convention the reference itself relies on
     (flair_hub/models/flair_model.py:302-306, 506-518): encoder.out_channels = [in, 0, C, 2C, 4C, 8C];
   * `relative_position_bias_table` as a state-dict key of shape [(2 ws - 1)^2, heads]
-    (flair_hub/models/checkpoint.py:33-56, 265-271).
+    (flair_hub/models/checkpoint.py:33-56, 265-271);
+  * the ENCODER against an independent implementation that IS installed here: transformers.SwinModel (HuggingFace's port
+    of the original Microsoft code).  With the weights mapped (qkv split, timm's merge-at-stage-start vs HF's
+    merge-at-stage-end) the four stage outputs agree to 2e-5 on a 224 px input, where no stage needs padding
+    (tests/test_oracle_goldens.py::test_swin_oracle_matches_the_huggingface_implementation): window partition, the
+    shifted-window mask, the relative-position-bias indexing, the MLP and the patch-merging order are pinned.  What stays
+    unpinned is the padded case (timm rolls, then pads; HF pads, then rolls) and smp's UPerNet decoder.
 The ARITHMETIC is torch.nn.functional on CPU, i.e. the ATen ops timm / smp themselves call.
 
 State-dict key names follow timm's FeatureListNet flattening (`layers_0.blocks.0...`) under smp's `encoder.model.`,

@@ -512,3 +512,65 @@ def test_checkpoint_loader_resizes_swin_bias_tables(tmp_path):
     assert torch.equal(b, interpolate_bias_table(a, b))
     k2 = "encoder.model.layers_1.blocks.0.attn.qkv.weight"
     assert torch.equal(src.state_dict()[k2], dst.state_dict()[k2])
+
+
+def test_swin_oracle_matches_the_huggingface_implementation():
+    """An independent third-party implementation of the same published architecture is installed in this image
+    (transformers.SwinModel, a port of the original Microsoft code; timm itself is absent): on an input whose stage maps
+    are multiples of the window (224 px, window 7 -> 56 / 28 / 14 / 7: no padding anywhere, where timm pads after the roll
+    and HF before it) oracle/swin_upernet.py's encoder must reproduce its four stage outputs -- patch embedding, W-MSA /
+    SW-MSA with the shifted-window mask and the relative-position-bias indexing, MLP, the patch-merging order."""
+    transformers = pytest.importorskip("transformers")
+    import torch
+    from oracle.seeded_weights import fill_swin_state_dict
+    from oracle.swin_upernet import TimmUniversalEncoder
+    torch.manual_seed(0)
+    enc = TimmUniversalEncoder("swin_tiny_patch4_window7_224", 5, 224, drop_path_rate=0.0).eval()
+    enc.load_state_dict(fill_swin_state_dict(enc.state_dict()))
+    cfg = transformers.SwinConfig(image_size=224, patch_size=4, num_channels=5, embed_dim=96, depths=[2, 2, 6, 2],
+                                  num_heads=[3, 6, 12, 24], window_size=7, drop_path_rate=0.0, hidden_act="gelu",
+                                  layer_norm_eps=1e-5, qkv_bias=True)
+    hf = transformers.SwinModel(cfg, add_pooling_layer=False).eval()
+    hf_keys = set(hf.state_dict().keys())
+    split_names = ("q_proj", "k_proj", "v_proj") if any(".q_proj." in k for k in hf_keys) else None
+    sd = {}
+    for k, v in enc.state_dict().items():
+        k = k[len("model."):]
+        if k.startswith("patch_embed.proj"):
+            sd[k.replace("patch_embed.proj", "embeddings.patch_embeddings.projection")] = v
+        elif k.startswith("patch_embed.norm"):
+            sd[k.replace("patch_embed.norm", "embeddings.norm")] = v
+        else:
+            m = re.match(r"layers_(\d+)\.(.*)", k)
+            i, rest = int(m.group(1)), m.group(2)
+            if rest.startswith("downsample."):  # timm merges at the START of stage i, HF at the END of stage i - 1
+                sd[f"encoder.layers.{i - 1}.{rest}"] = v
+                continue
+            rest = rest.replace("norm1", "layernorm_before").replace("norm2", "layernorm_after")
+            rest = rest.replace("attn.relative_position_bias_table",
+                                "attention.relative_position_bias.relative_position_bias_table"
+                                if split_names else "attention.self.relative_position_bias_table")
+            rest = rest.replace("attn.proj", "attention.o_proj" if split_names else "attention.output.dense")
+            if ".attn.qkv." in "." + rest:
+                C = v.shape[0] // 3
+                names = split_names or ("attention.self.query", "attention.self.key", "attention.self.value")
+                for j, nm in enumerate(names):
+                    tgt = rest.replace("attn.qkv", ("attention." + nm) if split_names else nm)
+                    sd[f"encoder.layers.{i}.{tgt}"] = v[j * C:(j + 1) * C]
+                continue
+            sd[f"encoder.layers.{i}.{rest}"] = v
+    missing, unexpected = hf.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("relative_position_index" in k or k.startswith("layernorm.") for k in missing), missing
+    feats = {}
+    for i, layer in enumerate(hf.encoder.layers):
+        layer.blocks[-1].register_forward_hook(lambda mod, inp, out, i=i: feats.__setitem__(i, out[0] if isinstance(out, tuple) else out))
+    x = torch.randn(1, 5, 224, 224, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        ours = enc(x)[2:]
+        hf(x)
+    for i, f in enumerate(ours):
+        B, C, H, W = f.shape
+        ref = feats[i].reshape(B, H, W, C).permute(0, 3, 1, 2)
+        err = (f - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+        assert err <= 2e-5, (i, err)
