@@ -11,6 +11,11 @@ smp/timm are not installed here, so the ARCHITECTURE is restated from the publis
 torchvision sources and pinned only by
   * the parameter count smp publishes for Unet-ResNet34 (24,436,369 @ in=3, classes=1) and
   * the state-dict key names the reference itself hard-codes (flair_hub/models/checkpoint.py:225-228).
+Round 2: the ENCODER is additionally pinned against an independent implementation that is installed in this image,
+transformers.ResNetModel (layer_type 'basic', depths 3-4-6-3): with the weights mapped, the stem and the four stage
+outputs agree to 2e-5 in evaluation mode and with training-mode BatchNorm
+(tests/test_oracle_goldens.py::test_resnet34_encoder_oracle_matches_the_huggingface_implementation).  smp's UnetDecoder
+(nearest x2 + concat + two conv-BN-ReLU per block, 3x3 head) has no installed counterpart and stays restated.
 The ARITHMETIC is torch.nn.functional on CPU -- the very ATen ops smp would call -- so op-level
 parity with this file is parity with the reference's accelerator=cpu path ("parity unpinned" by
 reference-side vectors).

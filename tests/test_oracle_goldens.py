@@ -574,3 +574,50 @@ def test_swin_oracle_matches_the_huggingface_implementation():
         ref = feats[i].reshape(B, H, W, C).permute(0, 3, 1, 2)
         err = (f - ref).abs().max().item() / max(1.0, ref.abs().max().item())
         assert err <= 2e-5, (i, err)
+
+
+@pytest.mark.parametrize("train_mode", [False, True])
+def test_resnet34_encoder_oracle_matches_the_huggingface_implementation(train_mode):
+    """the conv stack's oracle is restated from smp 0.4.0 / torchvision, both absent.  An independent
+    implementation of the same published encoder IS installed: transformers.ResNetModel (layer_type 'basic', depths
+    3-4-6-3, widths 64-128-256-512 = ResNet-34).  With the weights mapped, oracle/unet_resnet34.ResNet34Encoder must
+    reproduce its stem and four stage outputs -- the 7x7 stride-2 stem, max-pool 3x3 / 2 / 1, BasicBlock wiring, where the
+    stride and the 1x1 projection shortcut sit -- in evaluation mode and with training-mode BatchNorm statistics."""
+    transformers = pytest.importorskip("transformers")
+    import torch
+    from oracle.seeded_weights import fill_state_dict
+    from oracle.unet_resnet34 import ResNet34Encoder
+    enc = ResNet34Encoder(5)
+    enc.load_state_dict(fill_state_dict(enc.state_dict()))
+    cfg = transformers.ResNetConfig(num_channels=5, embedding_size=64, hidden_sizes=[64, 128, 256, 512],
+                                    depths=[3, 4, 6, 3], layer_type="basic", hidden_act="relu",
+                                    downsample_in_first_stage=False)
+    hf = transformers.ResNetModel(cfg)
+    sd = {}
+    for k, v in enc.state_dict().items():
+        parts = k.split(".")
+        if parts[0] in ("conv1", "bn1"):
+            sd["embedder.embedder." + ("convolution." if parts[0] == "conv1" else "normalization.") + parts[-1]] = v
+            continue
+        stage, layer = int(parts[0][len("layer"):]) - 1, int(parts[1])
+        base = f"encoder.stages.{stage}.layers.{layer}."
+        if parts[2] == "downsample":
+            sd[base + "shortcut." + ("convolution." if parts[3] == "0" else "normalization.") + parts[-1]] = v
+        else:
+            idx = int(parts[2][-1]) - 1  # conv1 / bn1 -> layer.0, conv2 / bn2 -> layer.1
+            sd[base + f"layer.{idx}." + ("convolution." if parts[2].startswith("conv") else "normalization.") + parts[-1]] = v
+    hf.load_state_dict(sd, strict=True)
+    enc.train(train_mode)
+    hf.train(train_mode)
+    x = torch.randn(3, 5, 96, 64, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        ours = enc(x)                       # [x, stem @ 1/2, layer1 @ 1/4, ..., layer4 @ 1/32]
+        ref = hf(x, output_hidden_states=True).hidden_states  # (after embedder incl. max-pool, stage 1..4)
+    assert len(ref) == 5
+    for i in range(1, 5):
+        a, b = ours[i + 1], ref[i]
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item()), i
+    # the stem: HF's first hidden state is after its max-pool; pooling the oracle's stride-2 feature must give the same
+    pooled = torch.nn.functional.max_pool2d(ours[1], 3, 2, 1)
+    assert (pooled - ref[0]).abs().max().item() <= 2e-5 * max(1.0, ref[0].abs().max().item())
