@@ -20,6 +20,7 @@
 #define FFA_ACT_NONE 0
 #define FFA_ACT_GELU 1
 #define FFA_ACT_DGELU 2  // out = acc * gelu'(aux): the input gradient of fc2 carried through Mlp's activation
+#define FFA_ACT_RELU 3   // 1x1 convolution + folded BatchNorm + ReLU of the UPerNet decoder (evaluation)
 
 struct GemmArgs {
   const ffa_bf16* a;
@@ -165,6 +166,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs g) {
       for (int e = 0; e < 4; ++e) {
         v[e] = acc[i][j][e] + b4[e];
         if (g.act == FFA_ACT_GELU && !g.aux) v[e] = gemm_gelu(v[e]);
+        if (g.act == FFA_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
       }
       uint2 pk;
       pk.x = ffa_pack_bf16x2(v[0], v[1]);
@@ -346,6 +348,7 @@ __global__ void __launch_bounds__(512, 1) gemm256_bf16_kernel(GemmArgs g) {
         for (int e = 0; e < 4; ++e) {
           v[e] = acc[i][half * 4 + j][e] + b4[e];
           if (g.act == FFA_ACT_GELU && !g.aux) v[e] = gemm_gelu(v[e]);
+          if (g.act == FFA_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
         }
         uint2 pk;
         pk.x = ffa_pack_bf16x2(v[0], v[1]);
@@ -420,8 +423,9 @@ extern "C" int ffa_linear_ex(int dtype, const void* a, long long lda, const void
   FFA_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 8 == 0 && (!residual || (ldr >= N && ldr % 8 == 0)) &&
                   (!aux || (ldaux >= N && ldaux % 8 == 0)),
               "linear: row pitches must cover the row and be multiples of 8 elements");
-  FFA_REQUIRE(act == FFA_ACT_NONE || act == FFA_ACT_GELU || (act == FFA_ACT_DGELU && aux), "linear: activation %d", act);
-  FFA_REQUIRE(!(aux && act == FFA_ACT_NONE), "linear: an auxiliary tensor needs the GELU / DGELU epilogue");
+  FFA_REQUIRE(act == FFA_ACT_NONE || act == FFA_ACT_GELU || act == FFA_ACT_RELU || (act == FFA_ACT_DGELU && aux),
+              "linear: activation %d", act);
+  FFA_REQUIRE(!(aux && (act == FFA_ACT_NONE || act == FFA_ACT_RELU)), "linear: an auxiliary tensor needs the GELU / DGELU epilogue");
   FFA_REQUIRE(!row_scale || rows_per_scale > 0, "linear: rows_per_scale must be positive");
   GemmArgs g;
   g.a = (const ffa_bf16*)a;

@@ -796,47 +796,64 @@ extern "C" int ffa_window_attention(int dtype, const void* qkv, void* out, const
 // ------------------------------------------------------------------------------------------------
 // nn.AdaptiveAvgPool2d(S): out[b][i][j] = mean of in[b][floor(i H / S) : ceil((i+1) H / S)][... same for W]
 
+// one block per output cell: 256 threads = (C / 8 pieces, up to 32) x (8 or more pixel lanes) walk the cell's region
+// together and combine through LDS in a fixed order (the regions are up to the whole map for S = 1)
 template <typename T>
-__global__ void adaptive_avg_pool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int S) {
+__global__ void __launch_bounds__(256) adaptive_avg_pool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H,
+                                                                int W, int C, int S) {
+  __shared__ float red[256][8];
   const int CG = C / 8;
-  const long long total = (long long)B * S * S * CG;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int g = (int)(i % CG);
-    long long p = i / CG;
-    const int ox = (int)(p % S);
-    p /= S;
-    const int oy = (int)(p % S);
-    const long long b = p / S;
-    const int y0 = (oy * H) / S, y1 = ((oy + 1) * H + S - 1) / S;
-    const int x0 = (ox * W) / S, x1 = ((ox + 1) * W + S - 1) / S;
+  int cell = blockIdx.x;
+  const int ox = cell % S;
+  cell /= S;
+  const int oy = cell % S;
+  const long long b = cell / S;
+  const int y0 = (oy * H) / S, y1 = ((oy + 1) * H + S - 1) / S;
+  const int x0 = (ox * W) / S, x1 = ((ox + 1) * W + S - 1) / S;
+  const int rw = x1 - x0, npix = (y1 - y0) * rw;
+  const float inv = 1.0f / (float)npix;
+  for (int g0 = blockIdx.y * 32; g0 < CG; g0 += gridDim.y * 32) {
+    const int g = g0 + (threadIdx.x & 31), pl = threadIdx.x >> 5;  // piece, pixel lane 0..7
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int yy = y0; yy < y1; ++yy)
-      for (int xx = x0; xx < x1; ++xx) {
+    if (g < CG)
+      for (int p = pl; p < npix; p += 8) {
+        const int yy = y0 + p / rw, xx = x0 + p % rw;
         float v[8];
         ffa_load8<T>(x + ((b * H + yy) * W + xx) * C + g * 8, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += v[e];
       }
-    const float inv = 1.0f / (float)((y1 - y0) * (x1 - x0));
+    __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] *= inv;
-    ffa_store8<T>(y + i * 8, acc);
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    if (pl == 0 && g < CG) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v += red[r * 32 + (threadIdx.x & 31)][e];
+        o[e] = v * inv;
+      }
+      ffa_store8<T>(y + ((b * S + oy) * S + ox) * (long long)C + g * 8, o);
+    }
   }
 }
 
 extern "C" int ffa_adaptive_avg_pool(int dtype, const void* x, void* y, int B, int H, int W, int C, int S,
                                      hipStream_t stream) {
   FFA_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && S > 0, "adaptive_avg_pool: bad arguments");
-  const long long items = (long long)B * S * S * (C / 8);
+  const int CG = C / 8;
+  const dim3 grid((unsigned)(B * S * S), (unsigned)((CG + 31) / 32 < 8 ? (CG + 31) / 32 : 8));
   if (dtype == FFA_BF16)
-    hipLaunchKernelGGL(adaptive_avg_pool_kernel<ffa_bf16>, dim3(tf_grid(items)), dim3(FFA_TF_THREADS), 0, stream,
-                       (const ffa_bf16*)x, (ffa_bf16*)y, B, H, W, C, S);
+    hipLaunchKernelGGL(adaptive_avg_pool_kernel<ffa_bf16>, grid, dim3(256), 0, stream, (const ffa_bf16*)x, (ffa_bf16*)y,
+                       B, H, W, C, S);
   else
-    hipLaunchKernelGGL(adaptive_avg_pool_kernel<float>, dim3(tf_grid(items)), dim3(FFA_TF_THREADS), 0, stream,
-                       (const float*)x, (float*)y, B, H, W, C, S);
+    hipLaunchKernelGGL(adaptive_avg_pool_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (float*)y, B, H, W,
+                       C, S);
   return ffa_check_launch("adaptive_avg_pool");
 }
 

@@ -254,8 +254,12 @@ class FLAIR_HUB_Model(nn.Module):
         for key in feature_maps.keys():
             if torch.rand(1).item() < modalities_dropout_dict[key]:
                 real = self.fusion_handler.stage_channels[key]
-                noise = []
-                for t, c in zip(feature_maps[key], real):
+                maps = list(feature_maps[key])
+                # a transformer encoder's [input, 0-channel placeholder] pair is not part of stage_channels (and no
+                # decoder reads it): it stays as it is
+                lead = 2 if len(maps) > 2 and (maps[0].shape[-1] == 0 or maps[1].shape[-1] == 0) else 0
+                noise = maps[:lead]
+                for t, c in zip(maps[lead:], real):
                     b, h, w, cp = t.shape
                     bound = math.sqrt(6.0 / float(c * h * w + b * h * w))
                     n = torch.empty_like(t).uniform_(-bound, bound)

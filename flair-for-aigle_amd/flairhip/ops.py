@@ -910,7 +910,7 @@ def mask_images_(x: torch.Tensor, pad: torch.Tensor, value: float = 0.0) -> torc
 # --------------------------------------------------------------------------------------------------
 # Swin-Transformer / UPerNet (csrc/transformer.hip, csrc/gemm.hip)
 
-ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_DGELU, ACT_RELU = 0, 1, 2, 3
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,

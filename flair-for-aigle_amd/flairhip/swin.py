@@ -135,8 +135,9 @@ class _Operands:
     def __init__(self):
         self.cache: Dict[str, tuple] = {}
 
-    def get(self, tag: str, params: Sequence[Optional[torch.Tensor]], dtype: torch.dtype, build):
-        ver = tuple((None if p is None else (p._version, p.data_ptr())) for p in params) + (hnn.state_epoch(), dtype)
+    def get(self, tag: str, params: Sequence[Optional[torch.Tensor]], dtype: torch.dtype, build, extra=()):
+        ver = tuple((None if p is None else (p._version, p.data_ptr())) for p in params) + (hnn.state_epoch(), dtype) + \
+            tuple(extra)
         hit = self.cache.get(tag)
         if hit is None or hit[0] != ver:
             hit = (ver, build())
@@ -539,9 +540,28 @@ class HipUPerNetDecoder(nn.Module):
         self.fpn_stages = nn.ModuleList(
             _mod(skip_conv=(_conv_bn(c, pyramid_channels, 1) if c != 0 else nn.Identity())) for c in ch[1:])
         self.fpn_bottleneck = _conv_bn((len(ch) - 1) * pyramid_channels, segmentation_channels, 3, padding=1)
+        self._fold = _Operands()
         for m in self.modules():  # smp initialize_decoder
             if isinstance(m, hnn.HipConv2d):
                 nn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="relu")
+
+    def _conv1x1(self, x: torch.Tensor, seq) -> torch.Tensor:
+        """evaluation-mode relu(BatchNorm(conv1x1(x))): in bf16 the token GEMM with the folded operand (scale * W as bf16
+        [N, K], shift as its bias, ReLU in the epilogue) -- the PSP branches are GEMMs of 8 ... 288 tokens, which the
+        pixel-tiled convolution kernel serves badly; f32 keeps the convolution kernel"""
+        conv, bn = seq[0], seq[1]
+        if x.dtype != torch.bfloat16 or x.shape[-1] != conv.in_channels or conv.out_channels % 8:
+            return hnn.conv_bn_act(x, conv, bn, relu=True)
+
+        def build():
+            scale, shift = ops.bn_eval_params(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+            n = conv.out_channels
+            w = conv.weight.detach().float().view(n, -1) * scale[:n, None]
+            return w.to(torch.bfloat16).contiguous(), shift[:n].contiguous()
+        # the training kernels update the running statistics through raw pointers: their epoch counter is part of the key
+        w, b = self._fold.get(f"c{id(conv)}", (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var),
+                              torch.bfloat16, build, extra=(getattr(bn, "_stats_epoch", 0),))
+        return ops.linear(x, w, b, act=ops.ACT_RELU)
 
     @staticmethod
     def _is_updown(prev: torch.Tensor, size, target) -> bool:
@@ -584,15 +604,15 @@ class HipUPerNetDecoder(nn.Module):
         cat = torch.empty((B, h, w, 2 * C), dtype=x.dtype, device=x.device)
         ops.bilinear_slice(x, (h, w), out=cat, offset=0)  # same-size resize = copy into the slice
         for i, (s, blk) in enumerate(zip(self.sizes, self.psp.blocks)):
-            p = hnn.conv_bn_act(ops.adaptive_avg_pool(x, s), blk[1][0], blk[1][1], relu=True)
+            p = self._conv1x1(ops.adaptive_avg_pool(x, s), blk[1])
             ops.bilinear_slice(p, (h, w), out=cat, offset=C + i * q)
-        top = hnn.conv_bn_act(cat, self.psp.out_conv[0], self.psp.out_conv[1], relu=True)
+        top = self._conv1x1(cat, self.psp.out_conv)
         fpn = [top]
         updown = False
         for f, stage in zip(feats[1:], self.fpn_stages):
             size = (f.shape[1], f.shape[2])
             if f.shape[-1] != 0:
-                lat = hnn.conv_bn_act(f, stage.skip_conv[0], stage.skip_conv[1], relu=True)
+                lat = self._conv1x1(f, stage.skip_conv)
                 fpn.append(ops.bilinear_slice(fpn[-1], size, addend=lat))
             elif self._is_updown(fpn[-1], size, target):
                 updown = True  # x2 up + resize back = one 3-tap filter pass below; the stride-2 map is never written

@@ -206,6 +206,7 @@ int ffa_linear(int dtype, const void* a, long long lda, const void* w, const flo
  * gradient of Mlp.fc2 carried through the activation); row_scale[m / rows_per_scale] multiplies the result before the
  * residual add (timm's DropPath: 0 or 1 / keep_prob per sample). */
 #define FFA_ACT_DGELU 2
+#define FFA_ACT_RELU 3 /* relu(a w^T + bias): a 1x1 convolution with folded BatchNorm + ReLU on tokens */
 int ffa_linear_ex(int dtype, const void* a, long long lda, const void* w, const float* bias, const void* residual,
                   long long ldr, void* out, long long ldc, int M, int K, int N, int act, void* aux, long long ldaux,
                   const float* row_scale, int rows_per_scale, ffa_stream_t stream);

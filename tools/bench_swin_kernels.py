@@ -43,10 +43,15 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--kinds", default="linear,attn,ln")
     ap.add_argument("--blas", action="store_true", help="also time torch's (hipBLASLt) matmul on the same shapes")
+    ap.add_argument("--variant", default="base", choices=["base", "tiny"], help="Swin-B/w12 or Swin-T/w7 shapes")
+    ap.add_argument("--bwd", action="store_true", help="also time the weight-gradient GEMM and the attention backward")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B = args.batch
     stages = [(128, 128, 4), (64, 256, 8), (32, 512, 16), (16, 1024, 32)]  # map size, C, heads
+    win = 12
+    if args.variant == "tiny":
+        stages, win = [(128, 96, 3), (64, 192, 6), (32, 384, 12), (16, 768, 24)], 7
     kinds = args.kinds.split(",")
     if "linear" in kinds:
         print(f"{'shape':34s} {'us':>8s} {'TFLOP/s':>8s} {'HBM us@5TB/s':>12s}" + ("  hipBLASLt us  TF" if args.blas else ""))
@@ -69,18 +74,27 @@ def main():
                 if args.blas:
                     dt2 = timeit(lambda: torch.matmul(x, w.t()))
                     line += f"   {dt2 * 1e6:8.1f} {fl / dt2 / 1e12:5.0f}"
+                if args.bwd:
+                    dy = torch.randn(M, N, device=dev).to(torch.bfloat16)
+                    dt3 = timeit(lambda: ops.linear_wgrad(x, dy, with_bias=True))
+                    line += f"   wgrad {dt3 * 1e6:8.1f} us {fl / dt3 / 1e12:5.0f} TF"
                 print(line)
     if "attn" in kinds:
         for si, (S, C, heads) in enumerate(stages):
-            ws = min(12, S)
+            ws = min(win, S)
             qkv = torch.randn(B, S, S, 3 * C, device=dev).to(torch.bfloat16)
             bias = torch.randn(3 * C, device=dev)
             table = torch.randn((2 * ws - 1) ** 2, heads, device=dev)
             for shift in (0, ws // 2 if S > ws else 0):
                 dt = timeit(lambda: ops.window_attention(qkv, bias, table, heads, ws, shift, 32 ** -0.5))
                 byt = 2.0 * B * S * S * 4 * C
+                extra = ""
+                if args.bwd:
+                    dout = torch.randn(B, S, S, C, device=dev).to(torch.bfloat16)
+                    dtb = timeit(lambda: ops.window_attention_bwd(qkv, dout, bias, table, heads, ws, shift, 32 ** -0.5))
+                    extra = f"   bwd {dtb * 1e6:8.1f} us"
                 print(f"s{si + 1} attention map {S:3d} C={C:4d} heads {heads:2d} ws {ws} shift {shift}: {dt * 1e6:8.1f} us"
-                      f"  (HBM {byt / 5e12 * 1e6:6.1f} us @5TB/s)")
+                      f"  (HBM {byt / 5e12 * 1e6:6.1f} us @5TB/s)" + extra)
     if "ln" in kinds:
         for si, (S, C, _) in enumerate(stages):
             x = torch.randn(B, S, S, C, device=dev).to(torch.bfloat16)

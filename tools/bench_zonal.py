@@ -49,7 +49,7 @@ def main():
     cfg = unet_resnet34_config(in_channels=C, precision=args.precision)
     cfg["models"]["monotemp_model"]["arch"] = args.arch
     model = FLAIR_HUB_Model(cfg, {MOD: 512}).to(dev).eval()
-    for B in (args.batch, 32):
+    for B in ((args.batch,) if args.forward_only else (args.batch, 32)):
         x = torch.randn(B, C, 512, 512, device=dev)
         with torch.no_grad():
             for _ in range(3):
