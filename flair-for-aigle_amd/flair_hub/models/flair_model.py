@@ -240,10 +240,10 @@ class FLAIR_HUB_Model(nn.Module):
             norm = norm.to(x.device, torch.float32)
             if x.dtype == torch.uint8:
                 return ops.u8_nchw_to_nhwc(x.contiguous(), self.compute_dtype, norm[0].contiguous(),
-                                           norm[1].contiguous(), ops.pad_channels(enc.in_channels))
+                                           norm[1].contiguous(), getattr(enc, "input_pitch", ops.pad_channels(enc.in_channels)))
             return ops.raw_nchw_to_nhwc(x.contiguous(), self.compute_dtype, norm[0].contiguous(), norm[1].contiguous(),
-                                        ops.pad_channels(enc.in_channels))
-        return hnn.to_nhwc(x, self.compute_dtype, ops.pad_channels(enc.in_channels))
+                                        getattr(enc, "input_pitch", ops.pad_channels(enc.in_channels)))
+        return hnn.to_nhwc(x, self.compute_dtype, getattr(enc, "input_pitch", ops.pad_channels(enc.in_channels)))
 
     def modality_dropout(self, feature_maps: Dict[str, list], modalities_dropout_dict: Dict[str, float]):
         """Reference :328-352: with probability ``modalities_dropout_dict[mod]`` the modality's feature maps are

@@ -408,6 +408,9 @@ class HipSwinEncoder(nn.Module):
         if ws > 12:
             raise NotImplementedError(f"window size {ws} > 12")
         self.name, self.in_channels, self.img_size, self.patch = name, in_channels, img_size, patch
+        # channel pitch the model glue gives the NHWC input tensor: 8 instead of the conv stack's 16 halves the
+        # space-to-depth tensor and the K of the patch-embedding GEMM (3 ... 5 real channels)
+        self.input_pitch = 8 if in_channels <= 8 else ops.pad_channels(in_channels)
         self.dims = [dim * 2 ** i for i in range(4)]
         self.out_channels = [in_channels, 0] + self.dims
         model = nn.Module()
