@@ -60,8 +60,13 @@ __device__ __forceinline__ float gemm_dgelu(float x) {
   return cdf + x * ex * 0.39894228040143267794f;
 }
 
+// TT = 16-token tiles per wave: 4 -> the 128-token block tile described above; 2 -> 64 tokens per block, twice the blocks,
+// for launches that would leave most CUs with one block or none (small batches at the deep stages)
+template <int TT>
 __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GIMG];
+  constexpr int BM = 32 * TT;
+  constexpr int IMG = (BM + GBN) * GPITCH;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * IMG];
   // XCD-aware order: the 8 XCDs take consecutive workgroup ids round-robin; give each XCD a contiguous run of tiles so
   // that the feature blocks of one token panel (same A tile) share an L2
   const int nb = gridDim.x;
@@ -71,7 +76,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs g) {
     id = xcd < rem ? xcd * (per + 1) + loc : rem * (per + 1) + (xcd - rem) * per + loc;
   }
   const int bm = id / g.nblk_n, bn = id % g.nblk_n;
-  const int m0 = bm * GBM, n0 = bn * GBN;
+  const int m0 = bm * BM, n0 = bn * GBN;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int n = lane & 15, grp = lane >> 4;
@@ -84,7 +89,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int r = (tid >> 3) + 32 * j;
-    int ar = m0 + r;
+    int ar = m0 + (r < BM ? r : BM - 1);
     if (ar > g.M - 1) ar = g.M - 1;
     int wr = n0 + r;
     if (wr > g.N - 1) wr = g.N - 1;
@@ -99,57 +104,56 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs g) {
     if (kb > kmax) kb = kmax;              // past the end of a ragged last chunk: any valid piece, never multiplied
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      ra[j] = *reinterpret_cast<const ffa_u32x4*>(arow[j] + kb);
+      if (j < TT) ra[j] = *reinterpret_cast<const ffa_u32x4*>(arow[j] + kb);
       rw[j] = *reinterpret_cast<const ffa_u32x4*>(wrow[j] + kb);
     }
   };
   auto store_lds = [&](int buf) {
-    unsigned char* img = smem + buf * GIMG;
+    unsigned char* img = smem + buf * IMG;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      *reinterpret_cast<ffa_u32x4*>(img + soff[j]) = ra[j];
-      *reinterpret_cast<ffa_u32x4*>(img + GBM * GPITCH + soff[j]) = rw[j];
+      if (j < TT) *reinterpret_cast<ffa_u32x4*>(img + soff[j]) = ra[j];
+      *reinterpret_cast<ffa_u32x4*>(img + BM * GPITCH + soff[j]) = rw[j];
     }
   };
 
-  ffa_f32x4 acc[4][4];  // [feature tile][token tile]
+  ffa_f32x4 acc[4][TT];  // [feature tile][token tile]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = ffa_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TT; ++j) acc[i][j] = ffa_f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (g.K + GBK - 1) / GBK;
   load_regs(0);
   store_lds(0);
   if (nk > 1) load_regs(1);
   __syncthreads();
-  const int tok_base = (wm * 64 + n) * GPITCH + grp * 16;
-  const int fea_base = GBM * GPITCH + (wn * 64 + n) * GPITCH + grp * 16;
+  const int tok_base = (wm * 16 * TT + n) * GPITCH + grp * 16;
+  const int fea_base = BM * GPITCH + (wn * 64 + n) * GPITCH + grp * 16;
   for (int c = 0; c < nk; ++c) {
     if (c + 1 < nk) store_lds((c + 1) & 1);
     if (c + 2 < nk) load_regs(c + 2);
-    const unsigned char* img = smem + (c & 1) * GIMG;
+    const unsigned char* img = smem + (c & 1) * IMG;
     const int ksteps = (g.K - c * GBK) >= GBK ? 2 : 1;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       if (ks < ksteps) {
-        ffa_bf16x8 fw[4], ft[4];
+        ffa_bf16x8 fw[4], ft[TT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          fw[i] = *reinterpret_cast<const ffa_bf16x8*>(img + fea_base + i * 16 * GPITCH + ks * 64);
-          ft[i] = *reinterpret_cast<const ffa_bf16x8*>(img + tok_base + i * 16 * GPITCH + ks * 64);
-        }
+        for (int i = 0; i < 4; ++i) fw[i] = *reinterpret_cast<const ffa_bf16x8*>(img + fea_base + i * 16 * GPITCH + ks * 64);
+#pragma unroll
+        for (int j = 0; j < TT; ++j) ft[j] = *reinterpret_cast<const ffa_bf16x8*>(img + tok_base + j * 16 * GPITCH + ks * 64);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], ft[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], ft[j], acc[i][j], 0, 0, 0);
       }
     }
     __syncthreads();
   }
 
   // ---- epilogue: bias + activation in registers, the wave's 64 x 64 tile through LDS, residual + store by rows
-  unsigned char* ep = smem + wave * (64 * GEP);
+  unsigned char* ep = smem + wave * (16 * TT * GEP);
   const int fcol0 = n0 + wn * 64;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -160,7 +164,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs g) {
       b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < TT; ++j) {
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -179,9 +183,9 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs g) {
   const int fp = lane & 7;
   const int col = fcol0 + fp * 8;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < 2 * TT; ++j) {
     const int t = (lane >> 3) + 8 * j;
-    const int row = m0 + wm * 64 + t;
+    const int row = m0 + wm * 16 * TT + t;
     if (row < g.M && col < g.N) {
       ffa_u32x4 v = *reinterpret_cast<const ffa_u32x4*>(ep + t * GEP + fp * 16);
       if (g.residual || g.aux || g.row_scale) {  // block-uniform
@@ -448,7 +452,12 @@ extern "C" int ffa_linear_ex(int dtype, const void* a, long long lda, const void
   g.nblk_n = (N + GBN - 1) / GBN;
   const long long blocks = (long long)((M + GBM - 1) / GBM) * g.nblk_n;
   FFA_REQUIRE(blocks < (1LL << 31), "linear: grid too large");
-  hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g);
+  if (blocks < 384) {  // fewer than 1.5 blocks per CU: 64-token tiles double the grid
+    const long long blocks64 = (long long)((M + 63) / 64) * g.nblk_n;
+    hipLaunchKernelGGL(gemm_bf16_kernel<2>, dim3((unsigned)blocks64), dim3(256), 0, stream, g);
+  } else {
+    hipLaunchKernelGGL(gemm_bf16_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, stream, g);
+  }
   return ffa_check_launch("linear");
 }
 
