@@ -1,11 +1,21 @@
 """Tile dataset of the zonal loop -- counterpart of the reference's flair_zonal_detection/dataset.py
-(MultiModalSlicedDataset :24, _load_patch :89-117, __getitem__ :174-209), mono-temporal modalities.
+(MultiModalSlicedDataset :24, _load_patch :89-117, _process_time_series_patch :121-169, __getitem__ :174-209).
 
 Per tile and modality: a boundless windowed read of the tile box (zero fill outside the raster, bilinear
 resample to the modality's patch size) followed by the per-channel (x - mean) / std normalisation of
 flair_hub/data/utils_data/norm.py:37-44 ('custom'); 'without' leaves values as they are.
 
+Time-series modalities ('<SENSOR>_TS', :100-104, :121-169): all T x C bands of the stack are read for the tile box, reshaped
+to [T, C, h, w] (no normalisation, as in the reference), optionally filtered by the Sentinel-2 cloud / snow mask raster
+(nearest-neighbour read, filter_time_series) and / or averaged per month or half-month (temporal_average); the day offsets
+to the reference date ride along as '<SENSOR>_DATES'.
+
 Differences from the reference, all on the host side of the boundary:
+  * cloud filtering is decided PER TILE and does not touch the dataset's date table: the reference overwrites
+    self.diff_dates with the first tile's surviving dates (dataset.py:155-156), after which every later tile reads the
+    wrong number of bands; tiles of one batch may then hold different numbers of dates -- collate with
+    ``pad_series_collate`` (zero-padded like the training pipeline's pad_collate_flair: all-zero dates are what the
+    U-TAE treats as padding)
   * the raster objects are duck-typed (flair_zonal_detection.raster) instead of rasterio-only
   * the '<MOD>_RAW' copy and the zero '<TASK>' label of the reference (dataset.py:194-207; 3 MB + 19.9 MB
     of H2D traffic per tile that the model never reads) are only emitted with ``reference_batch_schema=True``;
@@ -47,8 +57,6 @@ class MultiModalSlicedDataset(Dataset):
     def __init__(self, dataframe, modality_cfgs: Dict[str, Dict[str, Any]], patch_size_dict: Dict[str, int],
                  ref_date_str: str, modalities_config: Dict[str, Any], reference_batch_schema: bool = False,
                  device_normalize: bool = False) -> None:
-        if any(m.endswith("_TS") for m in modality_cfgs):
-            raise NotImplementedError("time-series modalities are not implemented on libflairhip yet")
         self.df = dataframe
         self.modalities = modality_cfgs
         self.modalities_config = modalities_config
@@ -59,6 +67,57 @@ class MultiModalSlicedDataset(Dataset):
         # the device normalise (ffa_u8_nchw_to_nhwc): a quarter of the PCIe bytes, no per-tile float work here
         self.device_normalize = device_normalize and not reference_batch_schema
         self.readers = {m: open_raster(cfg["input_img_path"]) for m, cfg in modality_cfgs.items()}
+        # Sentinel-2 cloud / snow mask stack (2 bands per date), possibly at another resolution (:51-56)
+        self.mask_reader, self.mask_resolution_ratio = None, 1.0
+        s2 = modality_cfgs.get("SENTINEL2_TS")
+        if s2 and s2.get("filter_clouds") and "filter_clouds_img_path" in s2:
+            self.mask_reader = open_raster(s2["filter_clouds_img_path"])
+            self.mask_resolution_ratio = self.readers["SENTINEL2_TS"].res[0] / self.mask_reader.res[0]
+        self.series_dates = self._init_series_dates()
+
+    def _init_series_dates(self):
+        """per time-series modality: acquisition dates (dates_txt, one YYYYMMDD per line) and their day offsets to the
+        reference month-day of the same year (:60-87)"""
+        from datetime import datetime
+        ref_month, ref_day = (int(v) for v in self.ref_date_str.split("-"))
+        out = {}
+        for mod, cfg in self.modalities.items():
+            if not mod.endswith("_TS"):
+                continue
+            if not cfg.get("dates_txt"):
+                raise ValueError(f"'dates_txt' is required for the time-series modality '{mod}' (one YYYYMMDD per line, "
+                                 "in the band order of the stack)")
+            with open(cfg["dates_txt"]) as f:
+                strs = [line.strip() for line in f if line.strip()]
+            if not strs:
+                raise ValueError(f"'dates_txt' file for '{mod}' is empty.")
+            dates = [datetime.strptime(d, "%Y%m%d") for d in strs]
+            out[mod] = {"dates": dates,
+                        "diff_dates": np.array([(d - datetime(d.year, ref_month, ref_day)).days for d in dates])}
+        return out
+
+    def _load_series(self, mod: str, bounds, cfg, patch_size: int):
+        """-> (float32 [T', C, h, w], float32 [T'] day offsets) of one tile"""
+        from flair_hub.data.utils_data.sentinel import filter_time_series, reshape_sentinel, temporal_average
+        info = self.series_dates[mod]
+        dates, diffs = list(info["dates"]), np.asarray(info["diff_dates"])
+        C = len(cfg["channels"])
+        reader = self.readers[mod]
+        if reader.count < C * len(dates):
+            raise ValueError(f"'{mod}' has {reader.count} bands, {len(dates)} dates x {C} channels were announced")
+        patch = reader.read_bounds(list(range(1, C * len(dates) + 1)), bounds, patch_size)
+        patch = reshape_sentinel(np.asarray(patch, dtype=np.float32), C)
+        if mod == "SENTINEL2_TS" and self.mask_reader is not None:
+            hm = int(patch.shape[2] / self.mask_resolution_ratio)
+            msk = self.mask_reader.read_bounds(list(range(1, 2 * len(dates) + 1)), bounds, max(hm, 1), nearest=True)
+            keep = filter_time_series(reshape_sentinel(np.asarray(msk), 2))
+            if keep.sum() > 0:
+                patch, diffs = patch[keep], diffs[keep]
+                dates = [d for d, k in zip(dates, keep) if k]
+        if cfg.get("temporal_average", False):
+            patch, diffs = temporal_average(patch, dates, period=cfg.get("average_period", "monthly"),
+                                            ref_date=self.ref_date_str)
+        return np.ascontiguousarray(patch, dtype=np.float32), np.ascontiguousarray(diffs, dtype=np.float32)
 
     def __len__(self) -> int:
         return len(self.df)
@@ -107,6 +166,11 @@ class MultiModalSlicedDataset(Dataset):
         bounds = self._tile_box(row)
         out: Dict[str, torch.Tensor] = {}
         for mod, cfg in self.modalities.items():
+            if mod.endswith("_TS"):
+                series, diffs = self._load_series(mod, bounds, cfg, self.patch_sizes[mod])
+                out[mod] = torch.from_numpy(series)
+                out[mod.replace("_TS", "_DATES")] = torch.from_numpy(diffs)
+                continue
             patch = self._load_patch(self.readers[mod], bounds, cfg, self.patch_sizes[mod])
             ncfg = cfg.get("normalization", {})
             if self.device_normalize and patch.dtype in RAW_DTYPES and self.norm_vectors(mod) is not None:
@@ -123,6 +187,23 @@ class MultiModalSlicedDataset(Dataset):
                 k = len(self.modalities_config["labels_configs"][task]["value_name"])
                 out[task] = torch.zeros((k, ref_size, ref_size), dtype=torch.float32)
         return out
+
+
+def pad_series_collate(samples):
+    """default_collate for zonal tiles whose time series may differ in length (per-tile cloud filtering): series and
+    their date vectors are zero-padded at the end to the batch's longest (all-zero dates = padded dates for the U-TAE,
+    the convention of flair_hub.data.utils_data.padding.pad_collate_flair)"""
+    from torch.utils.data import default_collate
+    keys = samples[0].keys()
+    out = {}
+    for k in keys:
+        vals = [s[k] for s in samples]
+        if torch.is_tensor(vals[0]) and (k.endswith("_TS") or k.endswith("_DATES")) and len({v.shape[0] for v in vals}) > 1:
+            T = max(v.shape[0] for v in vals)
+            vals = [torch.cat([v, v.new_zeros((T - v.shape[0],) + tuple(v.shape[1:]))]) if v.shape[0] < T else v
+                    for v in vals]
+        out[k] = default_collate(vals)
+    return out
 
 
 class TileBatcher:

@@ -29,7 +29,7 @@ from torch.utils.data import DataLoader
 
 from flairhip import ops
 from flair_zonal_detection.config import config_recap_1, config_recap_2, load_config, validate_config
-from flair_zonal_detection.dataset import MultiModalSlicedDataset, TileBatcher
+from flair_zonal_detection.dataset import MultiModalSlicedDataset, TileBatcher, pad_series_collate
 from flair_zonal_detection.model_utils import build_inference_model, compute_patch_sizes
 from flair_zonal_detection.postprocess import convert  # noqa: F401  (re-exported like the reference)
 from flair_zonal_detection.raster import ArrayRaster, make_window, open_raster
@@ -356,8 +356,11 @@ def run_inference(config_path, ref_raster=None, geozone=None, shard: Optional[Tu
     if TileBatcher.supports(dataset) and not config.get("num_worker", 0):
         loader = TileBatcher(dataset, config.get("batch_size", 8))  # uint8 tiles straight into pinned batch buffers
     else:
+        series = any(m.endswith("_TS") for m in dataset.modalities)
         loader = DataLoader(dataset, batch_size=config.get("batch_size", 8), num_workers=config.get("num_worker", 0),
-                            pin_memory=True)
+                            pin_memory=True, collate_fn=pad_series_collate if series else None)
+        if series and dataset.mask_reader is not None:
+            config["hip_graph"] = False  # per-tile cloud filtering: the number of dates changes from batch to batch
     outputs, _ = init_outputs(config, ref_img)
     if before_loop is not None:
         before_loop(outputs)

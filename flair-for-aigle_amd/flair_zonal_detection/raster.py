@@ -52,9 +52,10 @@ class RasterBase:
     def _native_dtype(self) -> np.dtype:
         return np.dtype(self.dtype).newbyteorder("=")
 
-    def read_bounds(self, indexes, bounds, out_size: int, out: np.ndarray = None) -> np.ndarray:
+    def read_bounds(self, indexes, bounds, out_size: int, out: np.ndarray = None, nearest: bool = False) -> np.ndarray:
         """Boundless read of the geographic box `bounds` = (left, bottom, right, top), zero fill outside the
-        raster, resampled to out_size x out_size when the box is not already that many pixels (bilinear).
+        raster, resampled to out_size x out_size when the box is not already that many pixels (bilinear; ``nearest``:
+        the source pixel under each output pixel centre, as Resampling.nearest does for the cloud masks).
         ``out`` ([len(indexes), out_size, out_size], the raster's dtype) receives the tile in place when given
         (the zonal loop passes a slot of its pinned batch buffer)."""
         l, b, r, t = bounds
@@ -77,6 +78,20 @@ class RasterBase:
             if ye > ys and xe > xs:
                 self._block(bands, ys, ye, xs, xe, out[:, ys - ri:ye - ri, xs - ci:xe - ci])
             return out
+        if nearest:
+            yy = np.floor(r0 + (np.arange(out_size) + 0.5) * (h / out_size)).astype(int)
+            xx = np.floor(c0 + (np.arange(out_size) + 0.5) * (w / out_size)).astype(int)
+            res_ = np.zeros((len(bands), out_size, out_size), dtype=dtype)
+            oky, okx = (yy >= 0) & (yy < self.height), (xx >= 0) & (xx < self.width)
+            if oky.any() and okx.any():
+                ya, yb, xa, xb = int(yy[oky].min()), int(yy[oky].max()) + 1, int(xx[okx].min()), int(xx[okx].max()) + 1
+                blk = np.empty((len(bands), yb - ya, xb - xa), dtype=dtype)
+                self._block(bands, ya, yb, xa, xb, blk)
+                res_[:, np.where(oky)[0][:, None], np.where(okx)[0][None, :]] = blk[:, (yy[oky] - ya)[:, None], (xx[okx] - xa)[None, :]]
+            if out is not None:
+                out[...] = res_
+                return out
+            return res_
         # generic path: bilinear sampling at output pixel centres, from the sub-block the samples touch
         ys = r0 + (np.arange(out_size) + 0.5) * (h / out_size) - 0.5
         xs = c0 + (np.arange(out_size) + 0.5) * (w / out_size) - 0.5

@@ -621,3 +621,19 @@ def test_resnet34_encoder_oracle_matches_the_huggingface_implementation(train_mo
     # the stem: HF's first hidden state is after its max-pool; pooling the oracle's stride-2 feature must give the same
     pooled = torch.nn.functional.max_pool2d(ours[1], 3, 2, 1)
     assert (pooled - ref[0]).abs().max().item() <= 2e-5 * max(1.0, ref[0].abs().max().item())
+
+
+def test_sentinel_patch_helpers_match_the_reference():
+    """tests/golden/sentinel_utils.npz: the reference's own reshape_sentinel / filter_time_series / temporal_average"""
+    import datetime
+    import numpy as np
+    from flair_hub.data.utils_data.sentinel import filter_time_series, reshape_sentinel, temporal_average
+    d = np.load(os.path.join(GOLD, "sentinel_utils.npz"))
+    assert np.array_equal(reshape_sentinel(d["reshape_in"], 10), d["reshape_out"])
+    assert np.array_equal(filter_time_series(d["filter_in"]), d["filter_out"]) and d["filter_out"].any()
+    assert np.array_equal(filter_time_series(d["filter2_in"]), d["filter2_out"]) and d["filter2_out"].sum() == 1
+    dates = [datetime.datetime.strptime(str(v), "%Y%m%d") for v in d["avg_days"]]
+    for tag, period in (("m", "monthly"), ("s", "semi-monthly")):
+        a, off = temporal_average(d["avg_in"], dates, period=period, ref_date="05-15")
+        assert a.shape == d[f"avg_{tag}_out"].shape and np.array_equal(off, d[f"avg_{tag}_days"])
+        assert np.allclose(a, d[f"avg_{tag}_out"], rtol=0, atol=1e-6)

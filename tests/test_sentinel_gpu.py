@@ -118,3 +118,89 @@ def test_aerial_plus_sentinel_training_step_matches_the_reference(cuda):
         ref = d["s2t_grad__" + k]
         rel = np.linalg.norm(named[k].grad.cpu().numpy() - ref) / np.linalg.norm(ref)
         assert rel <= 2e-2, f"{k}: relative gradient error {rel}"
+
+
+@pytest.mark.parametrize("filter_clouds", [False, True])
+def test_zonal_run_with_a_sentinel_time_series(cuda, tmp_path, filter_clouds):
+    """flair_zonal_detection with SENTINEL2_TS enabled next to the aerial mosaic (reference dataset.py:100-104,121-169):
+    the band stack is read per tile (bilinear, boundless), reshaped to [T, 10, h, w], optionally cloud-filtered per tile
+    (nearest-neighbour read of the 2-band-per-date mask stack), and the day offsets ride along as SENTINEL2_DATES; the
+    whole run_inference output equals the model applied by hand to the same batches"""
+    import yaml
+    from helpers import MOD, TASK
+    from flair_zonal_detection.dataset import pad_series_collate
+    from flair_zonal_detection.inference import (compute_patch_sizes, prep_config, prep_dataset, run_inference,
+                                                  generate_patches_from_reference)
+    from flair_zonal_detection.model_utils import build_inference_model
+    from flair_zonal_detection.raster import ArrayRaster
+    from flairhip import ops
+    from oracle.tile_bookkeeping import write_window
+    rng = np.random.default_rng(9)
+    H, W, res, patch, margin, T = 300, 400, 0.2, 128, 16, 5   # 80 m x 60 m: the modalities must share their bounds
+    left, top = 651992.36, 6860417.84
+    aerial = ArrayRaster(rng.integers(0, 255, (3, H, W)).astype(np.uint8), left, top, res)
+    # 10 m Sentinel stack (T dates x 10 bands), cloud / snow masks at 20 m
+    s2 = ArrayRaster(rng.normal(0.3, 0.2, (T * 10, 6, 8)).astype(np.float32), left, top, 10.0)
+    msk = np.zeros((T * 2, 3, 4), np.uint8)
+    msk[2 * 1 + 1] = 100          # date 1: cloudy everywhere
+    msk[2 * 3 + 1, :1] = 100      # date 3: cloudy in the northern third -> filtered for some tiles only
+    mask = ArrayRaster(msk, left, top, 20.0)
+    dates = tmp_path / "dates.txt"
+    dates.write_text("\n".join(["20210301", "20210420", "20210610", "20210815", "20211005"]) + "\n")
+    cfg = yaml.safe_load(open(os.path.join(GOLD, "zonal_config.yaml")))
+    cfg.update({"output_path": str(tmp_path), "output_name": "z", "img_pixels_detection": patch, "margin": margin,
+                "output_px_meters": res, "output_type": "argmax", "batch_size": 3, "num_worker": 0,
+                "hardware": {"precision": "fp32"}, "hip_graph": not filter_clouds})
+    cfg["modalities"]["inputs"]["SENTINEL2_TS"] = True
+    cfg["modalities"][MOD].update({"input_img_path": aerial, "channels": [1, 2, 3],
+                                   "normalization": {"type": "custom", "means": [105.66, 111.35, 102.18],
+                                                     "stds": [52.23, 45.62, 44.30]}})
+    cfg["modalities"]["SENTINEL2_TS"].update({"input_img_path": s2, "channels": list(range(1, 11)),
+                                              "dates_txt": str(dates), "filter_clouds": filter_clouds,
+                                              "filter_clouds_img_path": mask, "temporal_average": False})
+    cfg["tasks"] = [{"name": TASK, "active": True, "class_names": {i: f"c{i}" for i in range(19)}}]
+    # seeded checkpoint for the fused model (aerial U-Net + U-TAE): a placeholder file first, the configuration
+    # validator wants the path to exist
+    cfg["model_weights"] = str(tmp_path / "w.ckpt")
+    torch.save({"state_dict": {}}, cfg["model_weights"])
+    conf = prep_config(dict(cfg))
+    sizes = compute_patch_sizes(conf)
+    assert sizes["SENTINEL2_TS"] == 3  # 128 px x 0.2 m = 25.6 m of 10 m pixels
+    from flair_zonal_detection.model_utils import prepare_model_config
+    from flair_hub.models.flair_model import FLAIR_HUB_Model
+    probe = FLAIR_HUB_Model(prepare_model_config(conf), sizes)
+    sd = _fill(probe.state_dict())
+    torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}}, cfg["model_weights"])
+    got = run_inference(cfg)[TASK].data
+
+    # the same batches by hand
+    conf = prep_config(dict(cfg))
+    ref_img = aerial
+    tiles = generate_patches_from_reference(conf, ref_img, None)
+    model = build_inference_model(conf, compute_patch_sizes(conf)).to(cuda)
+    ds = prep_dataset(conf, tiles, compute_patch_sizes(conf))
+    item = ds[0]
+    assert item["SENTINEL2_TS"].shape[1:] == (10, 3, 3) and item["SENTINEL2_DATES"].shape == item["SENTINEL2_TS"].shape[:1]
+    lengths = sorted({int(ds[i]["SENTINEL2_TS"].shape[0]) for i in range(len(ds))})
+    assert lengths == ([3, 4] if filter_clouds else [5])  # date 1 always dropped, date 3 for the northern tiles
+    canvas = np.zeros_like(got)
+    bounds = tuple(aerial.bounds)
+    lefts, tops = np.asarray(tiles["left"]), np.asarray(tiles["top"])
+    for s in range(0, len(ds), 3):
+        batch = pad_series_collate([ds[i] for i in range(s, min(s + 3, len(ds)))])
+        idx = batch.pop("index").flatten().tolist()
+        inputs = {k: v.to(cuda) for k, v in batch.items()}
+        for m in ds.modalities:
+            if ds.delivers_raw(m):
+                inputs[m + "_NORM"] = torch.tensor(np.stack(ds.norm_vectors(m)), dtype=torch.float32, device=cuda)
+        with torch.no_grad():
+            lt, _ = model(inputs)
+        lg = lt[TASK]
+        pred = ops.predict_u8(lg._ffa_nhwc, lg._ffa_classes, "argmax", crop=(margin, margin, patch - 2 * margin,
+                                                                              patch - 2 * margin)).cpu().numpy()
+        for j, ti in enumerate(idx):
+            col, row, w, h, skip = write_window(lefts[ti], tops[ti], bounds, res, pred.shape[-2], pred.shape[-1])
+            if not skip:
+                canvas[:, row:row + h, col:col + w] = pred[j][:h, :w]
+    assert (got == canvas).mean() >= 0.9999
+    assert got.any()
