@@ -9,7 +9,7 @@ no third-party model zoo and no weight download is involved (smp's default ``enc
 
 Supported ``models.monotemp_model.arch`` values: ``resnet34-unet`` (BASELINE configs 1-3) and
 ``swin_{tiny,small,base,large}_patch4_window{7,12}_{224,384}-upernet`` (the reference's default arch and the fork's zonal
-configuration; BASELINE config 4; evaluation-mode forward, see flairhip/swin.py).  Any other encoder/decoder pair
+configuration; BASELINE config 4; evaluation in fp32/bf16 and bf16 training, see flairhip/swin.py).  Any other encoder/decoder pair
 raises NotImplementedError with the arch name.
 """
 from __future__ import annotations
@@ -66,7 +66,10 @@ class FLAIR_Monotemp(nn.Module):
         if decoder.lower() == "upernet":
             # smp.create_model("upernet", "tu-swin_...", img_size=img_size): the Swin is built for this input size
             if return_type == "encoder":
-                self.seg_model = swin.HipSwinEncoder(encoder, channels, img_size)
+                # timm's SwinTransformer default (stochastic depth 0.1); `drop_path_rate` under models.monotemp_model
+                # is an optional addition of this build (smp.create_model would take it as a keyword too)
+                dpr = float(config["models"]["monotemp_model"].get("drop_path_rate", 0.1))
+                self.seg_model = swin.HipSwinEncoder(encoder, channels, img_size, drop_path_rate=dpr)
             else:
                 dim = swin.parse_swin_name(encoder)[0]
                 enc_channels = [channels, 0] + [dim * 2 ** i for i in range(4)]

@@ -34,21 +34,23 @@ def _global_batches():
             for _ in range(STEPS)]
 
 
-def _build(seed_shift=0):
+def _build(seed_shift=0, arch=None):
     from flairhip.configs import unet_resnet34_config
     from flair_hub.tasks.module_setup import build_segmentation_module
     cfg = unet_resnet34_config(in_channels=5, precision="bf16", batch_size=B_RANK, total_steps=STEPS)
+    if arch:
+        cfg["models"]["monotemp_model"].update({"arch": arch, "drop_path_rate": 0.0})  # no per-rank random masks
     torch.manual_seed(cfg["hyperparams"]["seed"] + seed_shift)
     return build_segmentation_module(cfg, {MOD: TILE}, "train")
 
 
-def _worker(rank, port, out_dir):
+def _worker(rank, port, out_dir, arch=None):
     for p in (ROOT, os.path.join(ROOT, "flair-for-aigle_amd")):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(WORLD), FFA_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     from flair_hub.tasks.trainers import HipTrainer
-    task = _build(seed_shift=rank)  # ranks start from DIFFERENT weights: rank 0's must win
+    task = _build(seed_shift=rank, arch=arch)  # ranks start from DIFFERENT weights: rank 0's must win
     trainer = HipTrainer(max_epochs=1, max_steps=STEPS)  # process group + sharding happen inside
     assert trainer.world_size == WORLD and trainer.rank == rank
     trainer.fit(task, train_dataloaders=_global_batches())
@@ -146,3 +148,46 @@ def test_bucket_protocol_over_rccl_on_one_gpu(cuda, tmp_path):
         if k.startswith("fusion_handler."):
             continue  # gradient-less: the synchronised run zero-fills them, AdamW then applies weight decay alone
         assert torch.equal(v, res["rccl"][k]), k
+
+
+SWIN = "swin_tiny_patch4_window7_224-upernet"
+
+
+def test_two_ranks_train_swin_upernet_like_the_mean_gradient_step(cuda, tmp_path):
+    """the same flow for the transformer architecture: parameters that never receive a gradient (smp's unused FPNBlock of
+    the input image) are zero-filled in the buckets, the replicas stay bit-identical, and the result equals the
+    mean-gradient step up to the summation order of the attention backward's LDS atomics"""
+    mp.spawn(_worker, args=(_free_port(), str(tmp_path), SWIN), nprocs=WORLD, join=True)
+    w0, w1 = (torch.load(tmp_path / f"w{r}.pt") for r in range(WORLD))
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), f"replicas diverged at {k}"
+    task = _build(arch=SWIN).to(cuda)
+    task.train()
+
+    class _T:
+        estimated_stepping_batches = STEPS
+    task.trainer = _T()
+    opt_cfg = task.configure_optimizers()
+    opt, sched = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
+    params = dict(task.model.named_parameters())
+    start = {k: p.detach().clone() for k, p in params.items()}
+    for i, gb in enumerate(_global_batches()):
+        sums = {}
+        for r in range(WORLD):
+            sl = {k: v[r * B_RANK:(r + 1) * B_RANK].to(cuda) for k, v in gb.items()}
+            opt.zero_grad(set_to_none=True)
+            task.training_step(sl, i).backward()
+            for k, p in params.items():
+                if p.grad is not None:
+                    sums[k] = p.grad.clone() if k not in sums else sums[k] + p.grad
+        for k, p in params.items():
+            p.grad = sums[k] * (1.0 / WORLD) if k in sums else torch.zeros_like(p)
+        opt.step()
+        sched.step()
+    torch.cuda.synchronize()
+    unused = [k for k in params if "fpn_stages.4" in k]
+    assert unused, "the architecture is expected to hold gradient-less parameters"
+    for k, p in params.items():
+        moved = (p.detach() - start[k]).abs().max().item()
+        d = (p.detach().cpu() - w0[k]).abs().max().item()
+        assert d <= 0.05 * moved + 1e-7, f"{k}: data-parallel step differs from the mean-gradient step ({d} vs a move of {moved})"
