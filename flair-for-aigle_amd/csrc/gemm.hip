@@ -405,6 +405,88 @@ __global__ void __launch_bounds__(512, 1) gemm256_bf16_kernel(GemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// f32 parity mode of the token GEMM: plain FMA, 64 x 64 tile, the same epilogue order (bias -> activation -> row scale
+// -> residual).  It exists so that the transformer layers can be TRAINED in f32 and every gradient compared with the
+// CPU oracle at f32 tolerance (tests/test_swin_gpu.py); it is not a speed path (libm erff, no MFMA).
+struct GemmF32Args {
+  const float* a;
+  const float* w;
+  const float* bias;
+  const float* residual;
+  float* out;
+  float* aux;
+  const float* row_scale;
+  long long lda, ldr, ldc, ldaux;
+  int M, K, N, act, rows_per_scale;
+};
+
+__device__ __forceinline__ float gemm_gelu_f32(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gemm_dgelu_f32(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * expf(-0.5f * x * x) * 0.39894228040143267794f;
+}
+
+__global__ void __launch_bounds__(256) gemm_f32_kernel(GemmF32Args g) {
+  __shared__ float sa[16][68];  // [k][token]
+  __shared__ float sw[16][68];  // [k][feature]
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const long long m0 = (long long)blockIdx.x * 64;
+  const int n0 = blockIdx.y * 64;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int k0 = 0; k0 < g.K; k0 += 16) {
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+      const int r = i >> 4, c = i & 15;
+      const int k = k0 + c;
+      const long long m = m0 + r;
+      const int n = n0 + r;
+      sa[c][r] = (m < g.M && k < g.K) ? g.a[m * g.lda + k] : 0.f;
+      sw[c][r] = (n < g.N && k < g.K) ? g.w[(long long)n * g.K + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float av[4], wv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        av[i] = sa[kk][ty * 4 + i];
+        wv[i] = sw[kk][tx * 4 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * wv[j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long m = m0 + ty * 4 + i;
+    if (m >= g.M) continue;
+    const float sc = g.row_scale ? g.row_scale[m / g.rows_per_scale] : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n >= g.N) continue;
+      float v = acc[i][j] + (g.bias ? g.bias[n] : 0.f);
+      if (g.act == FFA_ACT_GELU) {
+        if (g.aux) g.aux[m * g.ldaux + n] = v;
+        v = gemm_gelu_f32(v);
+      } else if (g.act == FFA_ACT_DGELU) {
+        v *= gemm_dgelu_f32(g.aux[m * g.ldaux + n]);
+      } else if (g.act == FFA_ACT_RELU) {
+        v = fmaxf(v, 0.f);
+      }
+      v *= sc;
+      if (g.residual) v += g.residual[m * g.ldr + n];
+      g.out[m * g.ldc + n] = v;
+    }
+  }
+}
+
 // 256-tile kernel when the shape is MFMA-bound and fills the chip; FFA_GEMM_TILE=128|256 overrides (A/B runs)
 static bool gemm_use_256(int M, int K, int N) {
   static const char* force = getenv("FFA_GEMM_TILE");
@@ -421,8 +503,22 @@ extern "C" int ffa_linear_ex(int dtype, const void* a, long long lda, const void
                              const void* residual, long long ldr, void* out, long long ldc, int M, int K, int N, int act,
                              void* aux, long long ldaux, const float* row_scale, int rows_per_scale,
                              hipStream_t stream) {
-  FFA_REQUIRE(dtype == FFA_BF16, "linear: only the bf16 token GEMM is built (the f32 parity mode uses ffa_conv2d 1x1)");
+  FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "linear: dtype %d", dtype);
   FFA_REQUIRE(a && w && out && M > 0 && K > 0 && N > 0, "linear: bad arguments");
+  if (dtype == FFA_F32) {
+    FFA_REQUIRE(lda >= K && ldc >= N && (!residual || ldr >= N) && (!aux || ldaux >= N), "linear: row pitches must cover the row");
+    FFA_REQUIRE(act == FFA_ACT_NONE || act == FFA_ACT_GELU || act == FFA_ACT_RELU || (act == FFA_ACT_DGELU && aux),
+                "linear: activation %d", act);
+    FFA_REQUIRE(!row_scale || rows_per_scale > 0, "linear: rows_per_scale must be positive");
+    GemmF32Args f;
+    f.a = (const float*)a; f.w = (const float*)w; f.bias = bias; f.residual = (const float*)residual;
+    f.out = (float*)out; f.aux = (float*)aux; f.row_scale = row_scale;
+    f.lda = lda; f.ldr = ldr; f.ldc = ldc; f.ldaux = ldaux;
+    f.M = M; f.K = K; f.N = N; f.act = act; f.rows_per_scale = rows_per_scale > 0 ? rows_per_scale : 1;
+    FFA_REQUIRE((N + 63) / 64 < 65536, "linear: N too large");
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, stream, f);
+    return ffa_check_launch("linear");
+  }
   FFA_REQUIRE(K % 32 == 0 && N % 8 == 0, "linear: K = %d must be a multiple of 32 and N = %d of 8", K, N);
   FFA_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 8 == 0 && (!residual || (ldr >= N && ldr % 8 == 0)) &&
                   (!aux || (ldaux >= N && ldaux % 8 == 0)),
@@ -658,6 +754,82 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(const float* __rest
   }
 }
 
+// f32 parity mode of the weight-gradient GEMM: 64 n x 64 k tile per block over a contiguous token range, plain FMA,
+// the same [split][N][K] (+ [split][N]) slabs and the same fixed-order reduce as the bf16 kernel
+__global__ void __launch_bounds__(256) gemm_tn_f32_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          float* __restrict__ slab, float* __restrict__ bias_slab,
+                                                          long long ldy, long long ldx, int M, int N, int K, int nblk_n,
+                                                          int nblk_k, int rows_per_split) {
+  __shared__ float sdy[16][68];  // [token][n]
+  __shared__ float sx[16][68];   // [token][k]
+  int b = blockIdx.x;
+  const int bk = b % nblk_k;
+  b /= nblk_k;
+  const int bn = b % nblk_n;
+  const int split = b / nblk_n;
+  const int n0 = bn * 64, k0 = bk * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // tx -> k, ty -> n
+  const long long mbeg = (long long)split * rows_per_split;
+  long long mend = mbeg + rows_per_split;
+  if (mend > M) mend = M;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  float bsum = 0.f;
+  for (long long m0 = mbeg; m0 < mend; m0 += 16) {
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      const long long m = m0 + r;
+      sdy[r][c] = (m < mend && n0 + c < N) ? dy[m * ldy + n0 + c] : 0.f;
+      sx[r][c] = (m < mend && k0 + c < K) ? x[m * ldx + k0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mm = 0; mm < 16; ++mm) {
+      float dv[4], xv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dv[i] = sdy[mm][ty * 4 + i];
+        xv[i] = sx[mm][tx * 4 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += dv[i] * xv[j];
+    }
+    if (bias_slab && bk == 0 && threadIdx.x < 64) {
+#pragma unroll
+      for (int mm = 0; mm < 16; ++mm) bsum += sdy[mm][threadIdx.x];
+    }
+    __syncthreads();
+  }
+  float* out = slab + (long long)split * N * K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + ty * 4 + i, k = k0 + tx * 4 + j;
+      if (n < N && k < K) out[(long long)n * K + k] = acc[i][j];
+    }
+  if (bias_slab && bk == 0 && threadIdx.x < 64 && n0 + (int)threadIdx.x < N)
+    bias_slab[(long long)split * N + n0 + threadIdx.x] = bsum;
+}
+
+static void gemm_tn_plan_f32(int M, int N, int K, int* nblk_n, int* nblk_k, int* splits, int* rows_per_split) {
+  *nblk_n = (N + 63) / 64;
+  *nblk_k = (K + 63) / 64;
+  const long long tiles = (long long)*nblk_n * *nblk_k;
+  const long long chunks = ((long long)M + 63) / 64;
+  long long s = (1024 + tiles - 1) / tiles;
+  if (s > chunks) s = chunks;
+  if (s < 1) s = 1;
+  const long long per = (chunks + s - 1) / s;
+  *splits = (int)((chunks + per - 1) / per);
+  *rows_per_split = (int)(per * 64);
+}
+
 static void gemm_tn_plan(int M, int N, int K, int* nblk_n, int* nblk_k, int* splits, int* cps) {
   *nblk_n = (N + 127) / 128;
   *nblk_k = (K + 127) / 128;
@@ -673,21 +845,38 @@ static void gemm_tn_plan(int M, int N, int K, int* nblk_n, int* nblk_k, int* spl
 }
 
 extern "C" long long ffa_linear_wgrad_workspace_bytes(int M, int N, int K) {
-  int a, b, s, c;
+  int a, b, s, c, sf;
   gemm_tn_plan(M, N, K, &a, &b, &s, &c);
+  gemm_tn_plan_f32(M, N, K, &a, &b, &sf, &c);  // the entry point takes no dtype: room for either plan
+  if (sf > s) s = sf;
   return (long long)s * ((long long)N * K + N) * (long long)sizeof(float);
 }
 
 extern "C" int ffa_linear_wgrad(int dtype, const void* x, long long ldx, const void* dy, long long ldy, float* dw,
                                 float* dbias, int M, int K, int N, int accumulate, void* workspace,
                                 long long workspace_bytes, hipStream_t stream) {
-  FFA_REQUIRE(dtype == FFA_BF16, "linear_wgrad: bf16 only");
+  FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "linear_wgrad: dtype %d", dtype);
   FFA_REQUIRE(x && dy && dw && M > 0 && K >= 8 && N >= 8 && K % 8 == 0 && N % 8 == 0, "linear_wgrad: bad arguments");
   FFA_REQUIRE(ldx >= K && ldx % 8 == 0 && ldy >= N && ldy % 8 == 0, "linear_wgrad: row pitches must cover the rows");
   FFA_REQUIRE(((long long)N * K) % 4 == 0 && N % 4 == 0, "linear_wgrad: N * K and N must be multiples of 4");
   if (!workspace || workspace_bytes < ffa_linear_wgrad_workspace_bytes(M, N, K)) {
     ffa_set_error("linear_wgrad: workspace of %lld bytes needed", ffa_linear_wgrad_workspace_bytes(M, N, K));
     return FFA_ERR_WORKSPACE;
+  }
+  if (dtype == FFA_F32) {
+    int nbn, nbk, splits, rps;
+    gemm_tn_plan_f32(M, N, K, &nbn, &nbk, &splits, &rps);
+    float* slab = (float*)workspace;
+    float* bias_slab = dbias ? slab + (long long)splits * N * K : nullptr;
+    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3((unsigned)((long long)nbn * nbk * splits)), dim3(256), 0, stream,
+                       (const float*)dy, (const float*)x, slab, bias_slab, ldy, ldx, M, N, K, nbn, nbk, rps);
+    const long long nk = (long long)N * K;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((nk / 4 + 7) / 8)), dim3(256), 0, stream,
+                       (const float*)slab, dw, nk, splits, accumulate ? 1 : 0);
+    if (dbias)
+      hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((N / 4 + 7) / 8)), dim3(256), 0, stream,
+                         (const float*)bias_slab, dbias, (long long)N, splits, accumulate ? 1 : 0);
+    return ffa_check_launch("linear_wgrad");
   }
   GemmTnArgs g;
   g.dy = (const ffa_bf16*)dy;

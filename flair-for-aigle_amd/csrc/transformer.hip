@@ -1436,6 +1436,186 @@ __global__ void __launch_bounds__(64 * NW) window_attention_bwd_kernel(WinAttnAr
   }
 }
 
+// ---- f32 parity path of the backward: one block per (window, head), plain FMA, the two passes of the bf16 kernel
+// (pass A: one wave per query row -> row max, 1 / sum, delta, dQ, the bias-table gradient; pass B: one wave per key
+// column, probabilities recomputed from the saved row statistics -> dK, dV).  Same outputs and partial-row layout.
+__global__ void __launch_bounds__(256) window_attention_bwd_f32_kernel(WinAttnArgs a, const float* __restrict__ dout,
+                                                                       float* __restrict__ dqkv,
+                                                                       float* __restrict__ table_partial, int table_pitch,
+                                                                       float* __restrict__ pad_partial) {
+  constexpr int NMAX = 144;
+  __shared__ float sq[NMAX * 33], sk[NMAX * 33], sv[NMAX * 33], sdo[NMAX * 33];
+  __shared__ float sp[4][NMAX], sds[4][NMAX];
+  __shared__ float sm[NMAX], sli[NMAX], sdelta[NMAX];
+  __shared__ float stab[529], sdtab[529], spad[96];
+  __shared__ int slin[NMAX], srid[NMAX];
+  __shared__ long long soff[NMAX];
+  const int N = a.ws * a.ws;
+  const int head = blockIdx.y;
+  int w = blockIdx.x;
+  const int wx = w % a.nwx;
+  w /= a.nwx;
+  const int wy = w % a.nwy;
+  const int b = w / a.nwy;
+  const float* qkv = (const float*)a.qkv;
+  const int C3 = 3 * a.C;
+  const int TS = (2 * a.ws - 1) * (2 * a.ws - 1);
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const WinTok tk = win_token(a, b, wy, wx, i);
+    slin[i] = tk.lin;
+    srid[i] = tk.rid;
+    soff[i] = tk.off;
+  }
+  for (int i = threadIdx.x; i < TS; i += 256) {
+    stab[i] = a.table[i * a.heads + head];
+    sdtab[i] = 0.f;
+  }
+  if (threadIdx.x < 96) spad[threadIdx.x] = 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < N * 32; i += 256) {
+    const int t = i >> 5, d = i & 31;
+    const long long off = soff[t];
+    const int c = head * 32 + d;
+    float q, k, v, g = 0.f;
+    if (off >= 0) {
+      const float* p = qkv + off * C3;
+      q = p[c];
+      k = p[a.C + c];
+      v = p[2 * a.C + c];
+      g = dout[off * a.C + c];
+    } else {
+      q = a.qkv_bias[c];
+      k = a.qkv_bias[a.C + c];
+      v = a.qkv_bias[2 * a.C + c];
+    }
+    sq[t * 33 + d] = q;
+    sk[t * 33 + d] = k;
+    sv[t * 33 + d] = v;
+    sdo[t * 33 + d] = g;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int off0 = (a.ws - 1) * (2 * a.ws - 1) + (a.ws - 1);
+  const int d = lane & 31, half = lane >> 5;
+  float* p = sp[wave];
+  float* ds = sds[wave];
+  // pass A: queries
+  for (int i = wave; i < N; i += 4) {
+    if (soff[i] < 0) {  // a padding query has no output row: it contributes nothing (wave-uniform)
+      if (lane == 0) {
+        sm[i] = 0.f;
+        sli[i] = 0.f;
+        sdelta[i] = 0.f;
+      }
+      continue;
+    }
+    float mx = -INFINITY;
+    for (int j = lane; j < N; j += 64) {
+      float sdot = 0.f;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) sdot += sq[i * 33 + e] * sk[j * 33 + e];
+      float sv_ = sdot * a.scale + stab[slin[i] - slin[j] + off0];
+      if (srid[i] != srid[j]) sv_ += -100.0f;
+      p[j] = sv_;
+      mx = fmaxf(mx, sv_);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int j = lane; j < N; j += 64) {
+      const float e = expf(p[j] - mx);
+      p[j] = e;
+      sum += e;
+    }
+    sum = ffa_wave_sum(sum);
+    const float inv = 1.0f / sum;
+    float delta = 0.f;
+    for (int j = lane; j < N; j += 64) {
+      float dp = 0.f;
+#pragma unroll
+      for (int e = 0; e < 32; ++e) dp += sdo[i * 33 + e] * sv[j * 33 + e];
+      const float pr = p[j] * inv;
+      p[j] = pr;
+      ds[j] = dp;
+      delta += pr * dp;
+    }
+    delta = ffa_wave_sum(delta);
+    for (int j = lane; j < N; j += 64) {
+      const float g = p[j] * (ds[j] - delta);
+      ds[j] = g;
+      unsafeAtomicAdd(&sdtab[slin[i] - slin[j] + off0], g);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    float acc = 0.f;
+    for (int j = half; j < N; j += 2) acc += ds[j] * sk[j * 33 + d];
+    acc += __shfl_xor(acc, 32, 64);
+    if (half == 0) dqkv[soff[i] * C3 + head * 32 + d] = acc * a.scale;
+    if (lane == 0) {
+      sm[i] = mx;
+      sli[i] = inv;
+      sdelta[i] = delta;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // pass B: keys
+  for (int j = wave; j < N; j += 4) {
+    for (int i = lane; i < N; i += 64) {
+      float pr = 0.f, g = 0.f;
+      if (sli[i] != 0.f) {
+        float sdot = 0.f, dp = 0.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+          sdot += sq[i * 33 + e] * sk[j * 33 + e];
+          dp += sdo[i * 33 + e] * sv[j * 33 + e];
+        }
+        float sv_ = sdot * a.scale + stab[slin[i] - slin[j] + off0];
+        if (srid[i] != srid[j]) sv_ += -100.0f;
+        pr = expf(sv_ - sm[i]) * sli[i];
+        g = pr * (dp - sdelta[i]);
+      }
+      p[i] = pr;
+      ds[i] = g;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    float dv = 0.f, dk = 0.f;
+    for (int i = half; i < N; i += 2) {
+      dv += p[i] * sdo[i * 33 + d];
+      dk += ds[i] * sq[i * 33 + d];
+    }
+    dv += __shfl_xor(dv, 32, 64);
+    dk += __shfl_xor(dk, 32, 64);
+    dk *= a.scale;
+    if (half == 0) {
+      const long long off = soff[j];
+      if (off >= 0) {
+        dqkv[off * C3 + a.C + head * 32 + d] = dk;
+        dqkv[off * C3 + 2 * a.C + head * 32 + d] = dv;
+      } else {
+        unsafeAtomicAdd(&spad[32 + d], dk);
+        unsafeAtomicAdd(&spad[64 + d], dv);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  float* trow = table_partial + (long long)blockIdx.x * table_pitch;
+  for (int i = threadIdx.x; i < TS; i += 256) trow[i * a.heads + head] = sdtab[i];
+  if (head == 0)
+    for (int i = TS * a.heads + threadIdx.x; i < table_pitch; i += 256) trow[i] = 0.f;
+  if (pad_partial) {
+    const bool last_row = wy == a.nwy - 1, last_col = wx == a.nwx - 1;
+    if (last_row || last_col) {
+      const int slot = b * (a.nwx + a.nwy - 1) + (last_row ? wx : a.nwx + wy);
+      if (threadIdx.x < 96)
+        pad_partial[(long long)slot * (3 * a.C) + (threadIdx.x >> 5) * a.C + head * 32 + (threadIdx.x & 31)] =
+            spad[threadIdx.x];
+    }
+  }
+}
+
 static inline long long attn_bwd_table_pitch(int heads, int ws) {
   const long long n = (long long)(2 * ws - 1) * (2 * ws - 1) * heads;
   return (n + 7) / 8 * 8;
@@ -1459,7 +1639,7 @@ extern "C" int ffa_window_attention_bwd(int dtype, const void* qkv, const void* 
                                         const float* table, float* dtable, float* dbias_pad, int B, int H, int W, int C,
                                         int heads, int ws, int shift, float scale, void* workspace,
                                         long long workspace_bytes, hipStream_t stream) {
-  FFA_REQUIRE(dtype == FFA_BF16, "window_attention_bwd: bf16 only (no f32 training mode for the transformer layers)");
+  FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "window_attention_bwd: dtype %d", dtype);
   FFA_REQUIRE(qkv && dout && dqkv && qkv_bias && table && dtable && dbias_pad && B > 0 && H > 0 && W > 0 && heads > 0,
               "window_attention_bwd: bad arguments");
   FFA_REQUIRE(C == heads * 32, "window_attention_bwd: head dimension %d (only 32 is built)", heads ? C / heads : 0);
@@ -1486,7 +1666,10 @@ extern "C" int ffa_window_attention_bwd(int dtype, const void* qkv, const void* 
   float* pad_partial = pad_rows ? table_partial + nwin * pitch : nullptr;
   float* red = table_partial + nwin * pitch + pad_rows * 3 * C;
   const dim3 grid((unsigned)nwin, (unsigned)heads);
-  if (ws * ws <= 64)
+  if (dtype == FFA_F32)
+    hipLaunchKernelGGL(window_attention_bwd_f32_kernel, grid, dim3(256), 0, stream, a, (const float*)dout, (float*)dqkv,
+                       table_partial, pitch, pad_partial);
+  else if (ws * ws <= 64)
     hipLaunchKernelGGL((window_attention_bwd_kernel<4, 4>), grid, dim3(256), 0, stream, a, (const ffa_bf16*)dout,
                        (ffa_bf16*)dqkv, table_partial, pitch, pad_partial);
   else

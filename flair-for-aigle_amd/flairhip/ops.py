@@ -917,11 +917,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
            residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
            aux: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
            rows_per_scale: int = 0) -> torch.Tensor:
-    """nn.Linear on the last dimension of a bf16 token tensor [..., K]: act(x w^T + bias) * row_scale + residual.
-    w: bf16 [N, K] (nn.Linear.weight's layout), bias f32 [N].  aux ([..., N] bf16): with ACT_GELU it RECEIVES the
+    """nn.Linear on the last dimension of a token tensor [..., K]: act(x w^T + bias) * row_scale + residual.
+    w: [N, K] in x's dtype (nn.Linear.weight's layout), bias f32 [N].  aux ([..., N] bf16): with ACT_GELU it RECEIVES the
     pre-activation, with ACT_DGELU it supplies it (out = (x w^T) * gelu'(aux)).  row_scale f32 [M / rows_per_scale]."""
-    if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
-        raise ValueError("linear: bf16 operands only (f32 parity mode goes through conv2d 1x1)")
+    if x.dtype not in (torch.bfloat16, torch.float32) or w.dtype != x.dtype:
+        raise ValueError("linear: bf16 (MFMA token GEMM) or f32 (parity mode, plain FMA) operands of one dtype")
     if not x.is_contiguous() or not w.is_contiguous():
         raise ValueError("linear: operands must be contiguous")
     K = x.shape[-1]
@@ -1146,8 +1146,9 @@ def linear_wgrad(x: torch.Tensor, dy: torch.Tensor, out: Optional[torch.Tensor] 
                  with_bias: bool = False):
     """dW f32 [N, K] = dy^T x over all rows of the contiguous bf16 tensors x [..., K] and dy [..., N]; with_bias also
     returns db f32 [N] = column sums of dy from the same pass: (dW, db)"""
-    if x.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16 or not x.is_contiguous() or not dy.is_contiguous():
-        raise ValueError("linear_wgrad: contiguous bf16 operands only")
+    if x.dtype not in (torch.bfloat16, torch.float32) or dy.dtype != x.dtype or not x.is_contiguous() or \
+            not dy.is_contiguous():
+        raise ValueError("linear_wgrad: contiguous bf16 or f32 operands of one dtype")
     K, N = x.shape[-1], dy.shape[-1]
     M = x.numel() // K
     if dy.numel() // N != M:

@@ -1,4 +1,4 @@
-"""Swin-Transformer encoder + UPerNet decoder on libflairhip kernels (evaluation-mode forward).
+"""Swin-Transformer encoder + UPerNet decoder on libflairhip kernels.
 
 The reference's default architecture `swin_*-upernet` (configs/train/config_models.yaml:5; the fork's zonal
 configuration configs/config_model_zonal_segmentation.yaml:26 runs `swin_base_patch4_window12_384-upernet` on
@@ -20,14 +20,14 @@ Arithmetic (all NHWC, a token = a pixel of the stage's map):
 bf16 mode uses the hand-written token GEMM (csrc/gemm.hip); the f32 parity mode runs the same layers through the f32
 1x1 convolution kernel and a separate GELU pass.
 
-Training (bf16 only): every block half / merging / embedding / decoder resampling step is one autograd node whose
+Training: every block half / merging / embedding / decoder resampling step is one autograd node whose
 backward runs on the same library -- input gradients through the token GEMM with the TRANSPOSED weight (gelu' of the kept
 pre-activation and the DropPath factor in its epilogue), weight gradients through ffa_linear_wgrad (transposed-operand
 GEMM, deterministic split over the tokens), bias gradients through ffa_channel_sums, ffa_layer_norm_bwd (with the residual
 gradient added in the same pass), ffa_window_attention_bwd, ffa_bilinear_slice_bwd, ffa_adaptive_avg_pool_bwd.  timm's
 DropPath (stochastic depth, drop_path_rate = 0.1 by default, linearly increasing over the blocks) is the per-sample
-row scale of the residual GEMMs.  The f32 parity mode covers the evaluation forward only (the attention backward is a
-bf16 MFMA kernel): training in fp32 raises NotImplementedError, never a torch fallback.
+row scale of the residual GEMMs.  precision "32" trains through the same autograd nodes and entry points on their f32
+kernels (plain-FMA GEMMs and attention backward): a parity mode for gradient checks against the CPU oracle, not a speed path.
 """
 from __future__ import annotations
 
@@ -173,14 +173,15 @@ def _apply_linear(x: torch.Tensor, operand, n_out: int, act: int = ops.ACT_NONE,
 
 
 # --------------------------------------------------------------------------------------------------
-# training: autograd nodes (bf16)
+# training: autograd nodes (bf16 on the MFMA kernels; f32 parity mode on the plain-FMA kernels of the same entry points)
 
-def _wt(cache: _Operands, tag: str, weight: torch.Tensor):
-    """(W, W^T) in bf16, rebuilt when the parameter changes: forward operand [N,K] and input-gradient operand [K,N]"""
+def _wt(cache: _Operands, tag: str, weight: torch.Tensor, dtype: torch.dtype = torch.bfloat16):
+    """(W, W^T) in the compute dtype, rebuilt when the parameter changes: forward operand [N,K] and input-gradient
+    operand [K,N]"""
     def build():
-        w = weight.detach().to(torch.bfloat16).contiguous()
+        w = weight.detach().to(dtype).contiguous()
         return w, w.t().contiguous()
-    return cache.get(tag + ":wt", (weight,), torch.bfloat16, build)
+    return cache.get(tag + ":wt", (weight,), dtype, build)
 
 
 def _wgrad_bias(x: torch.Tensor, dy: torch.Tensor):
@@ -214,11 +215,11 @@ class _AttnHalf(torch.autograd.Function):
         rows = x.numel() // C
         stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
         h = ops.layer_norm(x, g1.detach(), b1.detach(), stats=stats)
-        wq, _ = _wt(enc._ops, tag + "qkv", wqkv)
+        wq, _ = _wt(enc._ops, tag + "qkv", wqkv, x.dtype)
         qkv = ops.linear(h, wq, bqkv.detach())
         scale = float((C // blk.heads) ** -0.5)
         att = ops.window_attention(qkv, bqkv.detach(), table.detach().contiguous(), blk.heads, blk.ws, blk.shift, scale)
-        wp, _ = _wt(enc._ops, tag + "proj", wproj)
+        wp, _ = _wt(enc._ops, tag + "proj", wproj, x.dtype)
         rps = x.shape[1] * x.shape[2]
         y = ops.linear(att, wp, bproj.detach(), residual=x, row_scale=rs, rows_per_scale=rps if rs is not None else 0)
         ctx.enc, ctx.blk, ctx.tag, ctx.scale, ctx.rps = enc, blk, tag, scale, rps
@@ -232,12 +233,12 @@ class _AttnHalf(torch.autograd.Function):
         C = blk.dim
         dy = dy.contiguous()
         dys = dy if rs is None else ops.scale_rows(dy, rs, ctx.rps)
-        _, wpt = _wt(enc._ops, tag + "proj", wproj)
+        _, wpt = _wt(enc._ops, tag + "proj", wproj, x.dtype)
         datt = ops.linear(dys, wpt)
         dwp, dbp = _wgrad_bias(att, dys)
         dqkv, dtable, dbpad = ops.window_attention_bwd(qkv, datt, bqkv.detach(), table.detach().contiguous(), blk.heads,
                                                        blk.ws, blk.shift, ctx.scale)
-        _, wqt = _wt(enc._ops, tag + "qkv", wqkv)
+        _, wqt = _wt(enc._ops, tag + "qkv", wqkv, x.dtype)
         dh = ops.linear(dqkv, wqt)
         dwq, dbq = _wgrad_bias(h, dqkv)
         dbq = dbq + dbpad
@@ -254,10 +255,10 @@ class _MlpHalf(torch.autograd.Function):
         rows = x.numel() // C
         stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
         h = ops.layer_norm(x, g2.detach(), b2.detach(), stats=stats)
-        w1b, _ = _wt(enc._ops, tag + "fc1", w1)
+        w1b, _ = _wt(enc._ops, tag + "fc1", w1, x.dtype)
         u = torch.empty(x.shape[:-1] + (4 * C,), dtype=x.dtype, device=x.device)
         a = ops.linear(h, w1b, bb1.detach(), act=ops.ACT_GELU, aux=u)
-        w2b, _ = _wt(enc._ops, tag + "fc2", w2)
+        w2b, _ = _wt(enc._ops, tag + "fc2", w2, x.dtype)
         rps = x.shape[1] * x.shape[2]
         y = ops.linear(a, w2b, bb2.detach(), residual=x, row_scale=rs, rows_per_scale=rps if rs is not None else 0)
         ctx.enc, ctx.blk, ctx.tag, ctx.rps = enc, blk, tag, rps
@@ -271,10 +272,10 @@ class _MlpHalf(torch.autograd.Function):
         C = blk.dim
         dy = dy.contiguous()
         dys = dy if rs is None else ops.scale_rows(dy, rs, ctx.rps)
-        _, w2t = _wt(enc._ops, tag + "fc2", w2)
+        _, w2t = _wt(enc._ops, tag + "fc2", w2, x.dtype)
         du = ops.linear(dys, w2t, act=ops.ACT_DGELU, aux=u)  # (dys W2) * gelu'(u)
         dw2, db2 = _wgrad_bias(a, dys)
-        _, w1t = _wt(enc._ops, tag + "fc1", w1)
+        _, w1t = _wt(enc._ops, tag + "fc1", w1, x.dtype)
         dh = ops.linear(du, w1t)
         dw1, db1 = _wgrad_bias(h, du)
         dx, dg, db = ops.layer_norm_bwd(x, dh, g2.detach(), stats, dres=dy)
@@ -289,7 +290,7 @@ class _PatchMerge(torch.autograd.Function):
         B, H, W, C = x.shape
         stats = torch.empty((B * (H // 2) * (W // 2), 2), dtype=torch.float32, device=x.device)
         m = ops.patch_merge_norm(x, g.detach(), b.detach(), stats=stats)
-        wr, _ = _wt(enc._ops, tag, wred)
+        wr, _ = _wt(enc._ops, tag, wred, x.dtype)
         y = ops.linear(m, wr)
         ctx.enc, ctx.tag = enc, tag
         ctx.save_for_backward(x, stats, m, g, wred)
@@ -299,7 +300,7 @@ class _PatchMerge(torch.autograd.Function):
     def backward(ctx, dy):
         x, stats, m, g, wred = ctx.saved_tensors
         dy = dy.contiguous()
-        _, wrt = _wt(ctx.enc._ops, ctx.tag, wred)
+        _, wrt = _wt(ctx.enc._ops, ctx.tag, wred, x.dtype)
         dm = ops.linear(dy, wrt)
         dw = _wgrad(m, dy, wred.shape[0], wred.shape[1])
         dx, dg, db = ops.patch_merge_norm_bwd(x, dm, g.detach(), stats)
@@ -316,7 +317,7 @@ class _PatchEmbed(torch.autograd.Function):
         w2 = torch.zeros(dim, ps, ps, cp, dtype=torch.float32, device=x.device)
         w2[..., :cin] = wproj.detach().permute(0, 2, 3, 1)
         s2d = ops.space_to_depth(x, ps)
-        t = ops.linear(s2d, w2.reshape(dim, -1).to(torch.bfloat16), bproj.detach())
+        t = ops.linear(s2d, w2.reshape(dim, -1).to(x.dtype), bproj.detach())
         stats = torch.empty((t.numel() // dim, 2), dtype=torch.float32, device=x.device)
         y = ops.layer_norm(t, g.detach(), b.detach(), stats=stats)
         ctx.geom = (ps, cp, dim, cin)
@@ -473,9 +474,6 @@ class HipSwinEncoder(nn.Module):
         if H % (self.patch * 8) or W % (self.patch * 8):
             raise ValueError(f"input {H}x{W} must be a multiple of {self.patch * 8}")
         train = self.training and torch.is_grad_enabled()
-        if train and x.dtype != torch.bfloat16:
-            raise NotImplementedError("HipSwinEncoder trains in bf16 only (the window-attention backward is a bf16 MFMA "
-                                      "kernel); the fp32 parity mode covers the evaluation forward")
         feats = [x, x.new_empty((B, H // 2, W // 2, 0))]
         m = self.model
         if train:

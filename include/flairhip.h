@@ -198,7 +198,8 @@ int ffa_mul(int dtype, const void* x, const void* m, void* y, long long n, ffa_s
 #define FFA_ACT_NONE 0
 #define FFA_ACT_GELU 1
 /* nn.Linear (+ nn.GELU) (+ residual add) on tokens: out[m][n] = act(sum_k a[m][k] w[n][k] + bias[n]) + residual[m][n];
- * w is nn.Linear.weight's own [N][K] layout in bf16.  bf16 only (the f32 parity mode runs ffa_conv2d 1x1). */
+ * w is nn.Linear.weight's own [N][K] layout in the dtype of a.  bf16: MFMA token GEMM (K % 32 == 0, N % 8 == 0, pitches
+ * % 8 == 0); f32: plain-FMA parity kernel with the same epilogues (any K, N), for gradient checks, not a speed path. */
 int ffa_linear(int dtype, const void* a, long long lda, const void* w, const float* bias, const void* residual,
                long long ldr, void* out, long long ldc, int M, int K, int N, int act, ffa_stream_t stream);
 /* The same GEMM with the training-time epilogues: act = FFA_ACT_GELU with `aux` != NULL also stores the (bf16) pre-activation
@@ -211,7 +212,8 @@ int ffa_linear_ex(int dtype, const void* a, long long lda, const void* w, const 
                   long long ldr, void* out, long long ldc, int M, int K, int N, int act, void* aux, long long ldaux,
                   const float* row_scale, int rows_per_scale, ffa_stream_t stream);
 /* nn.Linear's weight gradient dW[n][k] = sum_m dy[m][n] x[m][k] (f32 [N][K]; accumulate != 0 adds to dw): transposed-
- * operand MFMA GEMM over the tokens, split over token ranges with a fixed-order reduction (deterministic) */
+ * operand MFMA GEMM over the tokens, split over token ranges with a fixed-order reduction (deterministic); f32 operands take
+ * a plain-FMA kernel with the same slabs and reduction (parity mode) */
 long long ffa_linear_wgrad_workspace_bytes(int M, int N, int K);
 int ffa_linear_wgrad(int dtype, const void* x, long long ldx, const void* dy, long long ldy, float* dw,
                      float* dbias /* nullable: [N] column sums of dy from the same pass */, int M, int K, int N,
@@ -240,7 +242,7 @@ int ffa_patch_merge_norm_bwd(int dtype, const void* x, const void* dy, const flo
  * table [(2 ws - 1)^2][heads] is relative_position_bias_table */
 int ffa_window_attention(int dtype, const void* qkv, void* out, const float* qkv_bias, const float* table, int B, int H,
                          int W, int C, int heads, int ws, int shift, float scale, ffa_stream_t stream);
-/* backward of ffa_window_attention (bf16): dqkv [B][H][W][3C] from qkv and dout [B][H][W][C]; dtable [(2 ws - 1)^2][heads]
+/* backward of ffa_window_attention (bf16 MFMA kernel; f32 plain-FMA parity kernel): dqkv [B][H][W][3C] from qkv and dout [B][H][W][C]; dtable [(2 ws - 1)^2][heads]
  * and dbias_pad [3C] (gradient reaching the qkv bias through the padding tokens) are written (per-window partial rows in
  * the workspace, summed in a fixed order; only LDS atomics inside a block) */
 long long ffa_window_attention_bwd_workspace_bytes(int B, int H, int W, int C, int heads, int ws);
