@@ -496,6 +496,15 @@ def gen_sentinel(path_json, path_npz):
     json.dump(info, open(path_json, "w"), indent=1)
 
 
+SWIN_SAMPLED_GRADS = ["fusion_handler.conv_f.0.weight", "fusion_handler.conv_f.1.weight",
+                      "encoders.DEM_ELEV.seg_model.model.layers_1.blocks.1.attn.relative_position_bias_table",
+                      "encoders.DEM_ELEV.seg_model.model.patch_embed.proj.weight",
+                      "encoders.AERIAL_RGBI.seg_model.model.layers_1.blocks.0.mlp.fc1.weight",
+                      "encoders.AERIAL_RGBI.seg_model.model.layers_0.blocks.1.attn.qkv.bias",
+                      "main_decoders.AERIAL_LABEL-COSIA.seg_model.decoder.fpn_stages.1.skip_conv.0.weight",
+                      "main_decoders.ALL_LABEL-LPIS.seg_model.segmentation_head.0.weight"]
+
+
 def gen_swin(path_json, path_npz):
     """The reference's glue around a transformer-style encoder (smp's [input, 0-channel placeholder, f4, f8, f16, f32]
     feature list): FLAIR_HUB_Model.forward in evaluation mode with two Swin-T encoders (aerial 96x96x5 + DEM 64x64x2:
@@ -521,16 +530,40 @@ def gen_swin(path_json, path_npz):
     out = dict(x_aerial=xa.numpy(), x_dem=xd.numpy(), logits_cosia=lt["AERIAL_LABEL-COSIA"].numpy(),
                logits_lpis=lt["ALL_LABEL-LPIS"][:1].numpy(),
                logits_aux_cosia=la["aux_AERIAL_RGBI_AERIAL_LABEL-COSIA"][:1].numpy())
+    wsum = checksum(task.model.state_dict())  # before the training step moves the BatchNorm running statistics
+    # one training step of the reference's SegmentationTask (stochastic depth off: the draws of timm's DropPath are not
+    # reproducible across implementations; its arithmetic is tested separately): loss, predictions, gradients
+    for m in task.model.modules():
+        if hasattr(m, "drop_prob"):
+            m.drop_prob = 0.0
+    gt = torch.Generator().manual_seed(31)  # its own stream: the bias tables below keep their draws from `g`
+    tc = torch.randint(0, 19, (2, 96, 96), generator=gt)
+    tl = torch.randint(0, 23, (2, 96, 96), generator=gt)
+    tbatch = {"AERIAL_RGBI": xa, "DEM_ELEV": xd,
+              "AERIAL_LABEL-COSIA": torch.nn.functional.one_hot(tc, 19).permute(0, 3, 1, 2).float(), "ALL_LABEL-LPIS": tl}
+    task.train()
+    loss, preds, _ = task.step(tbatch, training=True)
+    loss.backward()
+    named = dict(task.model.named_parameters())
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in named.values() if p.grad is not None))
+    out.update(t_cosia=tc.numpy().astype(np.uint8), t_lpis=tl.numpy().astype(np.uint8),
+               preds_train_cosia=preds["AERIAL_LABEL-COSIA"].numpy().astype(np.uint8),
+               preds_train_lpis=preds["ALL_LABEL-LPIS"].numpy().astype(np.uint8),
+               **{"grad__" + k: named[k].grad.numpy() for k in SWIN_SAMPLED_GRADS})
     for i, (n_old, n_new, heads) in enumerate([(23, 15, 4), (13, 23, 3), (13, 13, 6)]):
         src = torch.randn(n_old * n_old, heads, generator=g)
         out[f"table{i}_in"] = src.numpy()
         out[f"table{i}_out"] = interpolate_bias_table(src, torch.zeros(n_new * n_new, heads)).numpy()
     np.savez_compressed(path_npz, **out)
-    info = {"weights_checksum": checksum(task.model.state_dict()), "logit_keys": sorted(lt.keys()),
+    info = {"weights_checksum": wsum, "logit_keys": sorted(lt.keys()),
             "aux_keys": sorted(la.keys()), "state_dict_keys": sorted(task.model.state_dict().keys()),
-            "encoder_out_channels": list(task.model.encoders["AERIAL_RGBI"].seg_model.out_channels)}
+            "encoder_out_channels": list(task.model.encoders["AERIAL_RGBI"].seg_model.out_channels),
+            "train": {"loss": hexf(loss.item()), "grad_norm": float(gn),
+                      "grad_norms": {k: float(p.grad.double().norm()) for k, p in named.items() if p.grad is not None},
+                      "unused_parameters": sorted(k for k, p in named.items() if p.grad is None)}}
     json.dump(info, open(path_json, "w"), indent=1)
-    print("  swin:", {k: tuple(v.shape) for k, v in lt.items()}, len(info["state_dict_keys"]), "keys")
+    print("  swin:", {k: tuple(v.shape) for k, v in lt.items()}, len(info["state_dict_keys"]), "keys; train loss",
+          f"{loss.item():.6f} grad-norm {float(gn):.6f}, {len(info['train']['unused_parameters'])} parameters without gradient")
 
 
 def main():

@@ -296,9 +296,61 @@ def _flair_swin(precision, sizes):
     from oracle.seeded_weights import fill_swin_state_dict
     cfg = fusion_unet_config(precision=precision)
     cfg["models"]["monotemp_model"]["arch"] = "swin_tiny_patch4_window7_224-upernet"
+    cfg["models"]["monotemp_model"]["drop_path_rate"] = 0.0  # the golden's training step has stochastic depth off
     task = build_segmentation_module(cfg, sizes, "train")
     task.model.load_state_dict(fill_swin_state_dict(task.model.state_dict()))
     return task.cuda().eval(), cfg
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_two_swin_encoders_fused_training_step_matches_the_reference_task(precision):
+    """tests/golden/swin_two_mod.*, "train": one step of the REFERENCE's SegmentationTask on that model (training-mode
+    BatchNorm, two task losses with weights 1 / 0.5, the auxiliary decoders outside the loss): loss, predictions, the
+    set of parameters without gradient, every parameter's gradient norm and eight sampled gradients"""
+    import json
+    import os
+    import numpy as np
+    from helpers import MOD, ROOT, TASK
+    gold = os.path.join(ROOT, "tests", "golden")
+    d = np.load(os.path.join(gold, "swin_two_mod.npz"))
+    info = json.load(open(os.path.join(gold, "swin_two_mod.json")))["train"]
+    task, cfg = _flair_swin(precision, {MOD: 96, "DEM_ELEV": 64})
+    tc = torch.from_numpy(d["t_cosia"]).long()
+    batch = {MOD: torch.from_numpy(d["x_aerial"]).cuda(), "DEM_ELEV": torch.from_numpy(d["x_dem"]).cuda(),
+             TASK: F.one_hot(tc, 19).permute(0, 3, 1, 2).float().cuda(),
+             "ALL_LABEL-LPIS": torch.from_numpy(d["t_lpis"]).long().cuda()}
+    task.train()
+    loss, preds, _ = task.step(batch, training=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_loss = float.fromhex(info["loss"])
+    named = dict(task.model.named_parameters())
+    assert sorted(k for k, p in named.items() if p.grad is None) == info["unused_parameters"]
+    fp32 = precision == "fp32"
+    assert abs(loss.item() - ref_loss) <= (2e-5 if fp32 else 2e-2) * ref_loss
+    agree = 0.9995 if fp32 else 0.9
+    assert (preds[TASK].cpu().numpy() == d["preds_train_cosia"]).mean() > agree
+    assert (preds["ALL_LABEL-LPIS"].cpu().numpy() == d["preds_train_lpis"]).mean() > agree
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in named.values() if p.grad is not None)).item()
+    assert abs(gn - info["grad_norm"]) <= (5e-3 if fp32 else 0.15) * info["grad_norm"]
+    if fp32:
+        # per-parameter norms: the DEM branch ends in a 2 x 2 map, its PSP BatchNorms see 2 ... 8 samples per channel and
+        # amplify f32 summation-order differences (the U-Net fusion fixture shows the same, tests/test_fusion_gpu.py)
+        off = [(k, named[k].grad.double().norm().item(), v) for k, v in info["grad_norms"].items()
+               if v > 1e-4 and abs(named[k].grad.double().norm().item() - v) > 5e-2 * v]
+        assert not off, off[:8]
+        # biases in front of a training-mode BatchNorm (fusion convolutions, the encoders' last fc2): exact gradient 0
+        zero = [k for k, v in info["grad_norms"].items() if v <= 1e-4]
+        assert len(zero) == 6 and all(named[k].grad.norm().item() <= 1e-5 for k in zero)
+    for k in [f[len("grad__"):] for f in d.files if f.startswith("grad__")]:
+        ref = d["grad__" + k]
+        got = named[k].grad.float().cpu().numpy()
+        rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        if fp32:
+            assert rel <= (5e-2 if "DEM_ELEV" in k else 1e-2), f"{k}: relative grad error {rel}"
+        else:
+            cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref)))
+            assert cos >= 0.8, f"{k}: cosine {cos}"
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
