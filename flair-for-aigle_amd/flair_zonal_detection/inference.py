@@ -54,22 +54,24 @@ def prep_config(config_path: str, model_ckpt_path: Optional[str] = None, model_t
     (scripts/run_fast_aigle_segmentation.py:75) and upstream FLAIR-HUB's one-argument call."""
     config = load_config(config_path) if isinstance(config_path, str) else config_path
     if images_folder is not None:
-        # the fork's caller feeds BD ORTHO JPEG-2000 tiles (scripts/run_fast_aigle_segmentation.py:88); JPEG-2000
-        # needs GDAL (rasterio) -- without it only GeoTIFF rasters can be opened (geotiff.py), so say so HERE instead
-        # of globbing *.jp2 and failing at the first read
+        # the fork's caller feeds BD ORTHO JPEG-2000 tiles (scripts/run_fast_aigle_segmentation.py:88): opened by
+        # rasterio (GDAL) when installed, else by jp2.Jp2Raster (OpenJPEG through Pillow); with neither only GeoTIFF
+        # rasters can be opened (geotiff.py), so say so HERE instead of globbing *.jp2 and failing at the first read
+        from flair_zonal_detection import jp2
         try:
             import rasterio  # type: ignore  # noqa: F401
-            patterns = ("*.jp2", "*.tif", "*.tiff")
+            can_jp2 = True
         except ImportError:
-            patterns = ("*.tif", "*.tiff")
-            if glob.glob(os.path.join(images_folder, "*.jp2")):
-                logger.warning("%s holds JPEG-2000 rasters, which need rasterio / GDAL (not installed): only "
-                               "GeoTIFF inputs are considered", images_folder)
+            can_jp2 = jp2.openjpeg_available()
+        patterns = ("*.jp2", "*.tif", "*.tiff") if can_jp2 else ("*.tif", "*.tiff")
+        if not can_jp2 and glob.glob(os.path.join(images_folder, "*.jp2")):
+            logger.warning("%s holds JPEG-2000 rasters, which need rasterio / GDAL or a Pillow with OpenJPEG (neither "
+                           "installed): only GeoTIFF inputs are considered", images_folder)
         rasters = sorted(p for pat in patterns for p in glob.glob(os.path.join(images_folder, pat)))
         if not rasters:
             raise FileNotFoundError(f"no raster ({', '.join(patterns)}) in {images_folder}"
-                                    + ("" if "*.jp2" in patterns else
-                                       "; JPEG-2000 inputs need rasterio, which is not installed"))
+                                    + ("" if can_jp2 else
+                                       "; JPEG-2000 inputs need rasterio or a Pillow with OpenJPEG, which are not installed"))
         config["modalities"]["AERIAL_RGBI"]["input_img_path"] = rasters[0]
     if model_ckpt_path is not None:
         config = overwrite_config(config, model_ckpt_path, model_threshold_filepath, result_folder, log_folder)

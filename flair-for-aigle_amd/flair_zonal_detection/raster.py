@@ -4,7 +4,7 @@ The reference talks to rasterio (GDAL) directly (flair_zonal_detection/dataset.p
 inference.py:157-208 / :342-352 GeoTIFF window writes).  rasterio is not installed in the build image, so the
 loop is written against the small duck-typed surface below: a real ``rasterio`` dataset satisfies it,
 ``ArrayRaster`` is the in-memory raster (north-up, square pixels), and ``geotiff.GeoTiffRaster`` /
-``geotiff.GeoTiffWriter`` are the file-backed ones.
+``geotiff.GeoTiffWriter`` / ``jp2.Jp2Raster`` are the file-backed ones.
 """
 from __future__ import annotations
 
@@ -220,13 +220,17 @@ class ArrayRaster(RasterBase):
 
 def open_raster(path_or_raster):
     """A raster object for a path, or the object itself when it already is one.  rasterio (GDAL) opens the path when
-    it is installed; without it GeoTIFF files are read by flair_zonal_detection.geotiff (JPEG-2000 mosaics and other
-    GDAL-only formats then raise)."""
+    it is installed; without it GeoTIFF files are read by flair_zonal_detection.geotiff and JPEG-2000 mosaics by
+    flair_zonal_detection.jp2 (other GDAL-only formats raise)."""
     if not isinstance(path_or_raster, (str, bytes, os.PathLike)):
         return path_or_raster
     try:
         import rasterio  # type: ignore
     except ImportError:
+        from flair_zonal_detection import jp2
+        path = os.fspath(path_or_raster)
+        if jp2.is_jpeg2000(path):
+            return jp2.Jp2Raster(path)
         from flair_zonal_detection.geotiff import GeoTiffRaster
-        return GeoTiffRaster(os.fspath(path_or_raster))
+        return GeoTiffRaster(path)
     return rasterio.open(path_or_raster)
