@@ -84,7 +84,8 @@ def test_linear_rejects_bad_shapes():
     with pytest.raises(FlairHipError):
         ops.linear(x, w)  # K not a multiple of 32
     with pytest.raises(ValueError):
-        ops.linear(x.float(), w.float())
+        ops.linear(x.float(), w)  # operands of different dtypes
+    assert ops.linear(x.float(), w.float()).abs().max().item() == 0.0  # f32 parity kernel: any K
 
 
 # ---------------------------------------------------------------------------------------------------- small kernels
