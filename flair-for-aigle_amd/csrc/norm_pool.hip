@@ -11,12 +11,29 @@
 
 #define FFA_EW_THREADS 256
 #define FFA_MAX_PARTIALS 1024
+#ifndef FFA_EW_UNROLL
+#define FFA_EW_UNROLL 4
+#endif
 
 static inline int ew_grid(long long items) {
   long long g = (items + FFA_EW_THREADS - 1) / FFA_EW_THREADS;
   if (g > 256 * 8) g = 256 * 8;
   if (g < 1) g = 1;
   return (int)g;
+}
+
+// grid for the per-channel streaming kernels: (grid * FFA_EW_THREADS) % (C / 8) == 0, so that a thread of the
+// grid-stride loop stays on one channel group
+static inline int ew_grid_c(long long nvec, int C) {
+  int a = C / 8, b = FFA_EW_THREADS;
+  while (b) {  // a = gcd(C / 8, FFA_EW_THREADS)
+    const int r = a % b;
+    a = b;
+    b = r;
+  }
+  const int m = (C / 8) / a;
+  const int g = ew_grid((nvec + FFA_EW_UNROLL - 1) / FFA_EW_UNROLL) / m * m;  // a thread moves FFA_EW_UNROLL vectors per iteration
+  return g < m ? m : g;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -197,11 +214,14 @@ extern "C" int ffa_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, i
 // pass used -- saves reading y (one third of the reduce pass, one quarter of the apply pass)
 struct StatOp {  // sum(x), sum(x^2)
   __device__ __forceinline__ void init(int, const float*, const float*, const float*, const float*) {}
-  template <typename T>
-  __device__ __forceinline__ void operator()(long long off, float (&a)[8], float (&b)[8], const T* x, const T*,
-                                             const T*, int) const {
+  template <typename R, typename T>
+  __device__ __forceinline__ void load(long long off, R& xr, R&, R&, const T* x, const T*, const T*, int) const {
+    xr.load(x + off);
+  }
+  template <typename R>
+  __device__ __forceinline__ void acc(float (&a)[8], float (&b)[8], const R& xr, const R&, const R&, int) const {
     float v[8];
-    ffa_load8<T>(x + off, v);
+    xr.get(v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       a[e] += v[e];
@@ -221,15 +241,22 @@ struct BnBwdOp {  // sum(g), sum(g * xhat) with g = dy masked by the ReLU
       sh[e] = (beta ? beta[c0 + e] : 0.f) - mean[e] * sc[e];
     }
   }
-  template <typename T>
-  __device__ __forceinline__ void operator()(long long off, float (&a)[8], float (&b)[8], const T* x, const T* dy,
-                                             const T* y, int relu) const {
+  template <typename R, typename T>
+  __device__ __forceinline__ void load(long long off, R& xr, R& gr, R& yr, const T* x, const T* dy, const T* y,
+                                       int relu) const {
+    xr.load(x + off);
+    gr.load(dy + off);
+    if (relu == 1) yr.load(y + off);
+  }
+  template <typename R>
+  __device__ __forceinline__ void acc(float (&a)[8], float (&b)[8], const R& xr, const R& gr, const R& yr,
+                                      int relu) const {
     float xv[8], gv[8];
-    ffa_load8<T>(x + off, xv);
-    ffa_load8<T>(dy + off, gv);
+    xr.get(xv);
+    gr.get(gv);
     if (relu == 1) {
       float yv[8];
-      ffa_load8<T>(y + off, yv);
+      yr.get(yv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) gv[e] = yv[e] > 0.f ? gv[e] : 0.f;
     } else if (relu == 2) {
@@ -241,6 +268,54 @@ struct BnBwdOp {  // sum(g), sum(g * xhat) with g = dy masked by the ReLU
       a[e] += gv[e];
       b[e] += gv[e] * (xv[e] - mean[e]) * rstd[e];
     }
+  }
+};
+
+// Streaming loops below keep FFA_EW_UNROLL independent 16-byte loads per operand in flight per thread (issued before
+// the first use) and consume them in index order: the sums are the same chains of additions as a plain loop.  With one
+// vector per iteration the wave waited out a full HBM round trip per 32 bytes (3.9 TB/s on the reduce at 4 waves/SIMD).
+#ifndef FFA_EW_UNROLL
+#define FFA_EW_UNROLL 4
+#endif
+// FFA_EW_CHUNK 1: the U vectors of an iteration are consecutive 4 KB rows of one block (a block streams U * 4 KB
+// contiguous bytes per operand per iteration); 0: they are a grid stride apart
+#ifndef FFA_EW_CHUNK
+#define FFA_EW_CHUNK 1
+#endif
+template <typename T>
+struct EwUnroll {
+  static constexpr int U = sizeof(T) == 2 ? FFA_EW_UNROLL : (FFA_EW_UNROLL > 2 ? 2 : FFA_EW_UNROLL);
+};
+
+// 8 channels as they sit in memory: loads land here and are widened to f32 only where they are used, so that U
+// vectors per operand in flight cost U * 4 registers (bf16), not U * 8
+template <typename T>
+struct Raw8;
+template <>
+struct Raw8<ffa_bf16> {
+  uint4 u;
+  __device__ __forceinline__ void load(const ffa_bf16* p) { u = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void get(float (&v)[8]) const {
+    v[0] = __uint_as_float(u.x << 16);
+    v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16);
+    v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16);
+    v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16);
+    v[7] = __uint_as_float(u.w & 0xffff0000u);
+  }
+};
+template <>
+struct Raw8<float> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = reinterpret_cast<const float4*>(p)[0];
+    b = reinterpret_cast<const float4*>(p)[1];
+  }
+  __device__ __forceinline__ void get(float (&v)[8]) const {
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
   }
 };
 
@@ -261,8 +336,22 @@ channel_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T
   if (pl < PL) {
     Op op;
     op.init(cg * 8, mean, rstd, gamma, beta);
-    for (long long p = (long long)blockIdx.x * PL + pl; p < npix; p += (long long)gridDim.x * PL)
-      op(p * C + cg * 8, a, b, x, dy, y, relu);
+    constexpr int U = EwUnroll<T>::U;
+    const long long S = (long long)gridDim.x * PL;
+    const long long us = FFA_EW_CHUNK ? PL : S;  // distance between the U pixels of one iteration
+    for (long long p = (long long)blockIdx.x * PL * (FFA_EW_CHUNK ? U : 1) + pl; p < npix; p += S * U) {
+      Raw8<T> xv[U], gv[U], yv[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long q = p + us * u;
+        ok[u] = q < npix;
+        op.load((ok[u] ? q : p) * C + cg * 8, xv[u], gv[u], yv[u], x, dy, y, relu);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (ok[u]) op.acc(a, b, xv[u], gv[u], yv[u], relu);
+    }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -482,30 +571,52 @@ extern "C" int ffa_bn_eval_params(int C, const float* gamma, const float* beta, 
 }
 
 template <typename T>
-__global__ void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
-                                const float* __restrict__ scale, const float* __restrict__ shift, long long nvec, int C,
-                                int relu) {
+__global__ void __launch_bounds__(FFA_EW_THREADS)
+bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                const float* __restrict__ scale, const float* __restrict__ shift, long long nvec, int C, int relu) {
+  constexpr int U = EwUnroll<T>::U;
   const int CG = C / 8;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % CG) * 8;
-    float v[8], sc[8], sh[8];
-    ffa_load8<T>(x + i * 8, v);
-    ffa_load8<float>(scale + c0, sc);
-    ffa_load8<float>(shift + c0, sh);
+  const long long S = (long long)gridDim.x * blockDim.x;
+  // U vectors per iteration: consecutive rows of the block when that keeps the thread's channel group, else a grid
+  // stride apart (which always does: ew_grid_c)
+  const bool chunk = FFA_EW_CHUNK && (FFA_EW_THREADS % CG == 0);
+  const long long us = chunk ? FFA_EW_THREADS : S;
+  long long i = blockIdx.x * (long long)blockDim.x * (chunk ? U : 1) + threadIdx.x;
+  // the launch makes the grid stride a multiple of C / 8 (ew_grid_c): a thread keeps its channel group for the whole
+  // loop and loads the per-channel vectors once
+  float sc[8], sh[8];
+  ffa_load8<float>(scale + ((int)i % CG) * 8, sc);
+  ffa_load8<float>(shift + ((int)i % CG) * 8, sh);
+  for (; i < nvec; i += S * U) {
+    Raw8<T> xr[U], rr[U];
+    bool ok[U];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-    if (res) {
-      float r[8];
-      ffa_load8<T>(res + i * 8, r);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += r[e];
+    for (int u = 0; u < U; ++u) {
+      const long long q = i + us * u;
+      ok[u] = q < nvec;
+      const long long o = (ok[u] ? q : i) * 8;
+      xr[u].load(x + o);
+      if (res) rr[u].load(res + o);
     }
-    if (relu) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    for (int u = 0; u < U; ++u) {
+      const long long q = i + us * u;
+      float v[8];
+      xr[u].get(v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+      if (res) {
+        float r[8];
+        rr[u].get(r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+      }
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (ok[u]) ffa_store8<T>(y + q * 8, v);
     }
-    ffa_store8<T>(y + i * 8, v);
   }
 }
 
@@ -515,10 +626,10 @@ extern "C" int ffa_bn_apply(int dtype, const void* x, const void* residual, void
   FFA_REQUIRE(x && y && scale && shift && C % 8 == 0, "bn_apply: bad arguments");
   const long long nvec = npix * (C / 8);
   if (dtype == FFA_BF16)
-    hipLaunchKernelGGL(bn_apply_kernel<ffa_bf16>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
+    hipLaunchKernelGGL(bn_apply_kernel<ffa_bf16>, dim3(ew_grid_c(nvec, C)), dim3(FFA_EW_THREADS), 0, stream,
                        (const ffa_bf16*)x, (const ffa_bf16*)residual, (ffa_bf16*)y, scale, shift, nvec, C, relu);
   else
-    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream, (const float*)x,
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid_c(nvec, C)), dim3(FFA_EW_THREADS), 0, stream, (const float*)x,
                        (const float*)residual, (float*)y, scale, shift, nvec, C, relu);
   return ffa_check_launch("bn_apply");
 }
@@ -548,36 +659,64 @@ bn_bwd_finalize_kernel(const float* __restrict__ ws, int nparts, int C, const fl
 }
 
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
-                                    const float* __restrict__ coef, T* __restrict__ dx, T* __restrict__ dres,
-                                    long long nvec, int C, int relu) {
+__global__ void __launch_bounds__(FFA_EW_THREADS)
+bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
+                    const float* __restrict__ coef, T* __restrict__ dx, T* __restrict__ dres, long long nvec, int C,
+                    int relu) {
+  constexpr int U = EwUnroll<T>::U;
   const int CG = C / 8;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % CG) * 8;
-    float xv[8], gv[8], kg[8], kx[8], k0[8];
-    ffa_load8<T>(x + i * 8, xv);
-    ffa_load8<T>(dy + i * 8, gv);
+  const long long S = (long long)gridDim.x * blockDim.x;
+  // U vectors per iteration: consecutive rows of the block when that keeps the thread's channel group, else a grid
+  // stride apart (which always does: ew_grid_c)
+  const bool chunk = FFA_EW_CHUNK && (FFA_EW_THREADS % CG == 0);
+  const long long us = chunk ? FFA_EW_THREADS : S;
+  long long i = blockIdx.x * (long long)blockDim.x * (chunk ? U : 1) + threadIdx.x;
+  float kg[8], kx[8], k0[8], sc[8], sh[8];
+  auto load_coef = [&](int c0) {
     ffa_load8<float>(coef + c0, kg);
     ffa_load8<float>(coef + C + c0, kx);
     ffa_load8<float>(coef + 2 * C + c0, k0);
-    if (relu == 1) {
-      float yv[8];
-      ffa_load8<T>(y + i * 8, yv);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) gv[e] = yv[e] > 0.f ? gv[e] : 0.f;
-    } else if (relu == 2) {
-      float sc[8], sh[8];
+    if (relu == 2) {
       ffa_load8<float>(coef + 3 * C + c0, sc);
       ffa_load8<float>(coef + 4 * C + c0, sh);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) gv[e] = (xv[e] * sc[e] + sh[e]) > 0.f ? gv[e] : 0.f;
     }
-    if (dres) ffa_store8<T>(dres + i * 8, gv);
-    float o[8];
+  };
+  load_coef(((int)i % CG) * 8);  // grid stride % (C / 8) == 0, see bn_apply_kernel
+  for (; i < nvec; i += S * U) {
+    Raw8<T> xr[U], gr[U], yr[U];
+    bool ok[U];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = kg[e] * gv[e] + kx[e] * xv[e] + k0[e];
-    ffa_store8<T>(dx + i * 8, o);
+    for (int u = 0; u < U; ++u) {
+      const long long q = i + us * u;
+      ok[u] = q < nvec;
+      const long long o = (ok[u] ? q : i) * 8;
+      xr[u].load(x + o);
+      gr[u].load(dy + o);
+      if (relu == 1) yr[u].load(y + o);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long q = i + us * u;
+      float xv[8], gv[8];
+      xr[u].get(xv);
+      gr[u].get(gv);
+      if (relu == 1) {
+        float yv[8];
+        yr[u].get(yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[e] = yv[e] > 0.f ? gv[e] : 0.f;
+      } else if (relu == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[e] = (xv[e] * sc[e] + sh[e]) > 0.f ? gv[e] : 0.f;
+      }
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = kg[e] * gv[e] + kx[e] * xv[e] + k0[e];
+      if (ok[u]) {
+        if (dres) ffa_store8<T>(dres + q * 8, gv);
+        ffa_store8<T>(dx + q * 8, o);
+      }
+    }
   }
 }
 
@@ -628,7 +767,7 @@ extern "C" int ffa_bn_bwd_stages(int dtype, const void* x, const void* dy, const
                          gamma, beta, mean, rstd, inv_count, dgamma, dbeta, coef);
     }
     if (stages & 2)
-      hipLaunchKernelGGL(bn_bwd_apply_kernel<ffa_bf16>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
+      hipLaunchKernelGGL(bn_bwd_apply_kernel<ffa_bf16>, dim3(ew_grid_c(nvec, C)), dim3(FFA_EW_THREADS), 0, stream,
                          (const ffa_bf16*)x, (const ffa_bf16*)dy, (const ffa_bf16*)y, coef, (ffa_bf16*)dx,
                          (ffa_bf16*)dres, nvec, C, relu);
   } else {
@@ -639,7 +778,7 @@ extern "C" int ffa_bn_bwd_stages(int dtype, const void* x, const void* dy, const
                          gamma, beta, mean, rstd, inv_count, dgamma, dbeta, coef);
     }
     if (stages & 2)
-      hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
+      hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid_c(nvec, C)), dim3(FFA_EW_THREADS), 0, stream,
                          (const float*)x, (const float*)dy, (const float*)y, coef, (float*)dx, (float*)dres, nvec, C,
                          relu);
   }
@@ -903,11 +1042,11 @@ extern "C" int ffa_bn_bwd_partials(int dtype, const void* x, const void* dy, con
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ffa_cdiv(C, 8)), dim3(FFA_FIN_THREADS), 0, stream, src, n, C, gamma, beta,
                      mean, rstd, inv_count, dgamma, dbeta, coef, 1);
   if (dtype == FFA_BF16)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<ffa_bf16>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<ffa_bf16>, dim3(ew_grid_c(nvec, C)), dim3(FFA_EW_THREADS), 0, stream,
                        (const ffa_bf16*)x, (const ffa_bf16*)dy, (const ffa_bf16*)nullptr, coef, (ffa_bf16*)dx,
                        (ffa_bf16*)nullptr, nvec, C, 2);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(nvec)), dim3(FFA_EW_THREADS), 0, stream, (const float*)x,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid_c(nvec, C)), dim3(FFA_EW_THREADS), 0, stream, (const float*)x,
                        (const float*)dy, (const float*)nullptr, coef, (float*)dx, (float*)nullptr, nvec, C, 2);
   return ffa_check_launch("bn_bwd_partials");
 }
@@ -917,19 +1056,19 @@ extern "C" int ffa_bn_bwd_partials(int dtype, const void* x, const void* dy, con
 // window order (the element ATen's CPU kernel keeps: strict '>' while scanning), recorded as a
 // window-local index 0..8 so the backward pass routes gradients exactly like the reference.
 
+// One block per output row (forward) / input row (backward), threads over (x, channel group): the index arithmetic is
+// one 32-bit divide per element (the flat 64-bit i -> (b, y, x, g) split cost more issue slots than the memory traffic).
 template <typename T>
-__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int B, int H,
-                                   int W, int C, int Ho, int Wo) {
-  const int CG = C / 8;
-  const long long total = (long long)B * Ho * Wo * CG;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int g = (int)(i % CG);
-    long long p = i / CG;
-    const int ox = (int)(p % Wo);
-    p /= Wo;
-    const int oy = (int)(p % Ho);
-    const long long b = p / Ho;
+__global__ void __launch_bounds__(FFA_EW_THREADS)
+maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int B, int H, int W, int C,
+                   int Ho, int Wo) {
+  const unsigned CG = C / 8;
+  const int oy = blockIdx.x % Ho;
+  const long long b = blockIdx.x / Ho;
+  const long long row = (long long)blockIdx.x * Wo * CG;
+  for (unsigned j = threadIdx.x; j < (unsigned)Wo * CG; j += FFA_EW_THREADS) {
+    const int ox = (int)(j / CG), g = (int)(j % CG);
+    const long long i = row + j;
     float best[8];
     int bi[8];
 #pragma unroll
@@ -966,19 +1105,17 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, u
 }
 
 template <typename T>
-__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, const T* __restrict__ add,
-                                   T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo) {
+__global__ void __launch_bounds__(FFA_EW_THREADS)
+maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, const T* __restrict__ add,
+                   T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo) {
   // gather form: input pixel (iy, ix) is tap (r, s) of output (oy, ox) when iy = 2*oy - 1 + r
-  const int CG = C / 8;
-  const long long total = (long long)B * H * W * CG;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int g = (int)(i % CG);
-    long long p = i / CG;
-    const int ix = (int)(p % W);
-    p /= W;
-    const int iy = (int)(p % H);
-    const long long b = p / H;
+  const unsigned CG = C / 8;
+  const int iy = blockIdx.x % H;
+  const long long b = blockIdx.x / H;
+  const long long row = (long long)blockIdx.x * W * CG;
+  for (unsigned j = threadIdx.x; j < (unsigned)W * CG; j += FFA_EW_THREADS) {
+    const int ix = (int)(j / CG), g = (int)(j % CG);
+    const long long i = row + j;
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -1016,12 +1153,13 @@ extern "C" int ffa_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* 
                                     hipStream_t stream) {
   FFA_REQUIRE(x && y && idx && C % 8 == 0, "maxpool_fwd: bad arguments");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const long long items = (long long)B * Ho * Wo * (C / 8);
+  FFA_REQUIRE(B > 0 && (long long)B * Ho < (1LL << 31), "maxpool_fwd: too many rows");
+  const int rows = B * Ho;
   if (dtype == FFA_BF16)
-    hipLaunchKernelGGL(maxpool_fwd_kernel<ffa_bf16>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+    hipLaunchKernelGGL(maxpool_fwd_kernel<ffa_bf16>, dim3(rows), dim3(FFA_EW_THREADS), 0, stream,
                        (const ffa_bf16*)x, (ffa_bf16*)y, idx, B, H, W, C, Ho, Wo);
   else
-    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(rows), dim3(FFA_EW_THREADS), 0, stream,
                        (const float*)x, (float*)y, idx, B, H, W, C, Ho, Wo);
   return ffa_check_launch("maxpool_fwd");
 }
@@ -1030,12 +1168,13 @@ extern "C" int ffa_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* id
                                     int H, int W, int C, hipStream_t stream) {
   FFA_REQUIRE(dy && dx && idx && C % 8 == 0, "maxpool_bwd: bad arguments");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const long long items = (long long)B * H * W * (C / 8);
+  FFA_REQUIRE(B > 0 && (long long)B * H < (1LL << 31), "maxpool_bwd: too many rows");
+  const int rows = B * H;
   if (dtype == FFA_BF16)
-    hipLaunchKernelGGL(maxpool_bwd_kernel<ffa_bf16>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+    hipLaunchKernelGGL(maxpool_bwd_kernel<ffa_bf16>, dim3(rows), dim3(FFA_EW_THREADS), 0, stream,
                        (const ffa_bf16*)dy, idx, (const ffa_bf16*)add, (ffa_bf16*)dx, B, H, W, C, Ho, Wo);
   else
-    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(ew_grid(items)), dim3(FFA_EW_THREADS), 0, stream,
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(rows), dim3(FFA_EW_THREADS), 0, stream,
                        (const float*)dy, idx, (const float*)add, (float*)dx, B, H, W, C, Ho, Wo);
   return ffa_check_launch("maxpool_bwd");
 }

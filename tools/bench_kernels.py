@@ -100,6 +100,28 @@ def bench_bn(args):
         for kname, fn, nbytes in runs:
             us = timeit(fn, iters=args.iters)
             print(f"{name:10s} {kname:10s} {us:9.1f} {nbytes / us / 1e3:9.0f}")
+    if args.only:
+        return
+    # the other streaming kernels of the step (algorithmic bytes)
+    x = torch.randn(B, 256, 256, 64, device=dev).to(dt)
+    yp, idx = ops.maxpool3x3s2_fwd(x)
+    dyp = torch.randn_like(yp)
+    add = torch.randn_like(x)
+    xin = torch.randn(B, 5, 512, 512, device=dev)
+    logits = torch.randn(B, 512, 512, 32, device=dev).to(dt)
+    tgt = torch.randint(0, 19, (B, 512, 512), device=dev, dtype=torch.uint8)
+    cw = torch.tensor([1.0] * 15 + [0.0] * 4, device=dev)
+    nb = x.numel() * 2
+    runs = [
+        ("maxpool", "fwd", lambda: ops.maxpool3x3s2_fwd(x), nb + nb // 4 + nb // 8),
+        ("maxpool", "bwd+add", lambda: ops.maxpool3x3s2_bwd(dyp, idx, (256, 256), add), 2 * nb + nb // 4 + nb // 8),
+        ("layout", "nchw->nhwc", lambda: ops.nchw_to_nhwc(xin, dt), xin.numel() * 4 + B * 512 * 512 * 16 * 2),
+        ("loss", "softmax_ce", lambda: ops.softmax_ce(logits, tgt, cw, 19, want_grad=True, want_pred=True),
+         2 * logits.numel() * 2 + 2 * tgt.numel()),
+    ]
+    for name, kname, fn, nbytes in runs:
+        us = timeit(fn, iters=args.iters)
+        print(f"{name:10s} {kname:10s} {us:9.1f} {nbytes / us / 1e3:9.0f}")
 
 
 def main():
