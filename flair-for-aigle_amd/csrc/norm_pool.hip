@@ -213,6 +213,7 @@ extern "C" int ffa_nhwc_to_nchw(int dtype, const void* src, float* dst, int B, i
 // was added before the ReLU), 2 = mask recomputed from x as (x*scale + shift > 0) with the same fma the forward
 // pass used -- saves reading y (one third of the reduce pass, one quarter of the apply pass)
 struct StatOp {  // sum(x), sum(x^2)
+  static constexpr bool kChunk = false;
   __device__ __forceinline__ void init(int, const float*, const float*, const float*, const float*) {}
   template <typename R, typename T>
   __device__ __forceinline__ void load(long long off, R& xr, R&, R&, const T* x, const T*, const T*, int) const {
@@ -231,6 +232,7 @@ struct StatOp {  // sum(x), sum(x^2)
 };
 
 struct BnBwdOp {  // sum(g), sum(g * xhat) with g = dy masked by the ReLU
+  static constexpr bool kChunk = true;
   float mean[8], rstd[8], sc[8], sh[8];
   __device__ __forceinline__ void init(int c0, const float* m, const float* r, const float* gamma, const float* beta) {
 #pragma unroll
@@ -338,8 +340,14 @@ channel_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T
     op.init(cg * 8, mean, rstd, gamma, beta);
     constexpr int U = EwUnroll<T>::U;
     const long long S = (long long)gridDim.x * PL;
-    const long long us = FFA_EW_CHUNK ? PL : S;  // distance between the U pixels of one iteration
-    for (long long p = (long long)blockIdx.x * PL * (FFA_EW_CHUNK ? U : 1) + pl; p < npix; p += S * U) {
+    // Forward statistics (StatOp) keep the grid-stride pixel order: with the in-order accumulation below every thread's
+    // sum is then the same chain of additions as a plain one-pixel-per-iteration loop, bit for bit.  (E[x^2] - mean^2 in
+    // f32 partials carries ~1e-7 * mean^2 / var of rounding; another grouping moves scale / shift by up to 1e-5 on
+    // low-variance channels, enough to flip a ReLU mask or two against the reference's evaluation on the 10 x 10 maps
+    // of the U-TAE golden: tools/utae_grad_margin.py.)  The backward sums feed no mask and take the contiguous rows.
+    constexpr bool CHUNK = FFA_EW_CHUNK && Op::kChunk;
+    const long long us = CHUNK ? PL : S;  // distance between the U pixels of one iteration
+    for (long long p = (long long)blockIdx.x * PL * (CHUNK ? U : 1) + pl; p < npix; p += S * U) {
       Raw8<T> xv[U], gv[U], yv[U];
       bool ok[U];
 #pragma unroll
