@@ -81,31 +81,66 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict
 // output elements per thread.  For few-channel inputs (the 5-band aerial tiles, pitch 16) the one-group-per-thread
 // kernel spends half its threads writing pad zeros and reads 4 bytes per lane: 2.3 TB/s of traffic; this one streams.
 template <typename T, int CP>
-__global__ void nchw_to_nhwc_x4_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C, long long hw) {
+__global__ void __launch_bounds__(FFA_EW_THREADS)
+nchw_to_nhwc_x4_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C, long long hw) {
   const long long quads = (long long)B * hw / 4;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < quads;
-       i += (long long)gridDim.x * blockDim.x) {
+  // bf16: the 4 pixels x CP channels of a thread are 128 contiguous bytes, so one store instruction of a wave would put
+  // 16 bytes on each of 64 different lines.  The block's 32 KB leave through LDS instead (pitch 9 pieces per thread:
+  // conflict-free both ways) as whole 16-byte pieces in memory order, 1 KB per wave instruction.
+  constexpr bool STAGE = sizeof(T) == 2 && CP == 16;
+  constexpr int NP = 4 * CP * (int)sizeof(T) / 16;  // 16-byte pieces per thread
+  __shared__ __align__(16) unsigned char stage[STAGE ? FFA_EW_THREADS * (NP + 1) * 16 : 16];
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i0 = blockIdx.x * (long long)blockDim.x; i0 < quads; i0 += stride) {
+    const long long i = i0 + threadIdx.x;
+    const bool live = i < quads;
     const long long pix = i * 4;
-    const long long b = pix / hw, p = pix % hw;
     float v[4][CP];
+    if (live) {
+      const long long b = pix / hw, p = pix % hw;
 #pragma unroll
-    for (int c = 0; c < CP; ++c) {
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < C) q = *reinterpret_cast<const float4*>(src + (b * C + c) * hw + p);
-      v[0][c] = q.x;
-      v[1][c] = q.y;
-      v[2][c] = q.z;
-      v[3][c] = q.w;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-      for (int g = 0; g < CP / 8; ++g) {
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = v[k][g * 8 + e];
-        ffa_store8<T>(dst + (pix + k) * CP + g * 8, o);
+      for (int c = 0; c < CP; ++c) {
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C) q = *reinterpret_cast<const float4*>(src + (b * C + c) * hw + p);
+        v[0][c] = q.x;
+        v[1][c] = q.y;
+        v[2][c] = q.z;
+        v[3][c] = q.w;
       }
+    }
+    if constexpr (STAGE) {
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int g = 0; g < CP / 8; ++g) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = v[k][g * 8 + e];
+            ffa_store8<T>(reinterpret_cast<T*>(stage + (threadIdx.x * (NP + 1) + k * (CP / 8) + g) * 16), o);
+          }
+      }
+      __syncthreads();
+      const long long left = quads - i0;
+      const int npc = (int)(left < FFA_EW_THREADS ? left : FFA_EW_THREADS) * NP;
+      uint4* out = reinterpret_cast<uint4*>(dst + i0 * 4 * CP);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const int idx = threadIdx.x + FFA_EW_THREADS * k;
+        if (idx < npc) out[idx] = *reinterpret_cast<const uint4*>(stage + ((idx / NP) * (NP + 1) + idx % NP) * 16);
+      }
+      __syncthreads();
+    } else if (live) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int g = 0; g < CP / 8; ++g) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = v[k][g * 8 + e];
+          ffa_store8<T>(dst + (pix + k) * CP + g * 8, o);
+        }
+    }
   }
 }
 
@@ -345,7 +380,9 @@ channel_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T
     // f32 partials carries ~1e-7 * mean^2 / var of rounding; another grouping moves scale / shift by up to 1e-5 on
     // low-variance channels, enough to flip a ReLU mask or two against the reference's evaluation on the 10 x 10 maps
     // of the U-TAE golden: tools/utae_grad_margin.py.)  The backward sums feed no mask and take the contiguous rows.
-    constexpr bool CHUNK = FFA_EW_CHUNK && Op::kChunk;
+    // (forward statistics of tensors large enough to saturate the partial rows take the contiguous rows too: the
+    // 64-channel 256^2 stem output, 268 MB, read at 2.5 TB/s a grid stride apart)
+    const bool CHUNK = FFA_EW_CHUNK && (Op::kChunk || gridDim.x == FFA_MAX_PARTIALS);
     const long long us = CHUNK ? PL : S;  // distance between the U pixels of one iteration
     for (long long p = (long long)blockIdx.x * PL * (CHUNK ? U : 1) + pl; p < npix; p += S * U) {
       Raw8<T> xv[U], gv[U], yv[U];

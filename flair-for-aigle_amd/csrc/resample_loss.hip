@@ -12,6 +12,8 @@
 //   * one-hot -> index (tasks_module.py:153)
 #include "ffa_common.h"
 
+#include <stdlib.h>
+
 #define FFA_EW_THREADS 256
 
 static inline int ew_grid(long long items) {
@@ -389,6 +391,156 @@ softmax_ce_kernel(const T* __restrict__ logits, const uint8_t* __restrict__ tgt,
   }
 }
 
+// The same per-pixel arithmetic with the tensor traffic staged through LDS (the default; FFA_CE_TILED=0 selects the
+// kernel above).  A thread that owns a pixel reads its 64 bytes as four 16-byte loads 64 bytes apart, so one wave
+// instruction touches 32 cache lines for 1 KB -- and writes dlogits the same way.  Here a block moves a tile of 256
+// pixels as whole 16-byte pieces in memory order (lane l <-> piece l: 1 KB per wave instruction, 8 lines), parks them in
+// LDS at an odd pitch (conflict-free ds_read_b128 when thread = pixel), each thread then works on its own pixel in
+// place, and the gradient leaves LDS in memory order again.  The next tile's pieces are requested before the current
+// tile's arithmetic.  Thread <-> pixel assignment, the arithmetic and the order of the loss partial sums are those of
+// softmax_ce_kernel: results are bit-identical.
+template <typename T>
+__global__ void __launch_bounds__(FFA_EW_THREADS)
+softmax_ce_tiled_kernel(const T* __restrict__ logits, const uint8_t* __restrict__ tgt, const float* __restrict__ w,
+                        const float* __restrict__ wsum, const float* __restrict__ grad_scale, T* __restrict__ dlogits,
+                        uint8_t* __restrict__ pred, float* __restrict__ parts, long long npix, int K, int Cp) {
+  constexpr int EPP = 16 / (int)sizeof(T);   // elements per 16-byte piece
+  constexpr int MAXP = FFA_CE_MAXK / EPP;    // pieces per pixel at the largest pitch: 4 (bf16) / 8 (f32)
+  __shared__ __align__(16) unsigned char tile[FFA_EW_THREADS * (MAXP + 1) * 16];
+  __shared__ float red[FFA_EW_THREADS / 64];
+  const int tid = threadIdx.x;
+  const int np = Cp / EPP;   // pieces per pixel
+  const int slots = np | 1;  // LDS pitch of a pixel in 16-byte slots: odd
+  float lsum = 0.f;
+  float gs = 0.f;
+  if (dlogits) gs = grad_scale[0] / wsum[0];
+  const long long ntiles = (npix + FFA_EW_THREADS - 1) / FFA_EW_THREADS;
+  int loff[MAXP];  // LDS byte offset of piece tid + 256 k of a tile
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int idx = tid + FFA_EW_THREADS * k;
+    loff[k] = ((idx / np) * slots + idx % np) * 16;
+  }
+  uint4 pre[MAXP];
+  auto gload = [&](long long ti) {
+    const long long base = ti * FFA_EW_THREADS;
+    const long long left = npix - base;
+    const int npc = (int)(left < FFA_EW_THREADS ? left : FFA_EW_THREADS) * np;
+    const uint4* src = reinterpret_cast<const uint4*>(logits + base * Cp);
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const int idx = tid + FFA_EW_THREADS * k;
+      if (k < np) pre[k] = idx < npc ? src[idx] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  long long ti = blockIdx.x;
+  if (ti < ntiles) gload(ti);
+  for (; ti < ntiles; ti += gridDim.x) {
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k)
+      if (k < np) *reinterpret_cast<uint4*>(tile + loff[k]) = pre[k];
+    __syncthreads();
+    if (ti + gridDim.x < ntiles) gload(ti + gridDim.x);
+    const long long i = ti * FFA_EW_THREADS + tid;
+    if (i < npix) {
+      unsigned char* mine = tile + tid * slots * 16;
+      float z[FFA_CE_MAXK];
+#pragma unroll
+      for (int v = 0; v < MAXP; ++v) {
+        if (v < np) {
+          const uint4 u = *reinterpret_cast<const uint4*>(mine + v * 16);
+          if constexpr (sizeof(T) == 2) {
+            z[v * 8 + 0] = __uint_as_float(u.x << 16);
+            z[v * 8 + 1] = __uint_as_float(u.x & 0xffff0000u);
+            z[v * 8 + 2] = __uint_as_float(u.y << 16);
+            z[v * 8 + 3] = __uint_as_float(u.y & 0xffff0000u);
+            z[v * 8 + 4] = __uint_as_float(u.z << 16);
+            z[v * 8 + 5] = __uint_as_float(u.z & 0xffff0000u);
+            z[v * 8 + 6] = __uint_as_float(u.w << 16);
+            z[v * 8 + 7] = __uint_as_float(u.w & 0xffff0000u);
+          } else {
+            z[v * 4 + 0] = __uint_as_float(u.x);
+            z[v * 4 + 1] = __uint_as_float(u.y);
+            z[v * 4 + 2] = __uint_as_float(u.z);
+            z[v * 4 + 3] = __uint_as_float(u.w);
+          }
+        }
+      }
+      float m = -INFINITY;
+      int am = 0;
+#pragma unroll
+      for (int k = 0; k < FFA_CE_MAXK; ++k) {
+        if (k < K && z[k] > m) {  // strict '>' keeps the lowest index on ties (torch.argmax)
+          m = z[k];
+          am = k;
+        }
+      }
+      float se = 0.f;
+#pragma unroll
+      for (int k = 0; k < FFA_CE_MAXK; ++k) {
+        if (k < K) {
+          z[k] = __expf(z[k] - m);
+          se += z[k];
+        }
+      }
+      const int t = tgt[i];
+      const float wt = (t < K) ? w[t] : 0.f;
+      const float inv = 1.f / se;
+      float zt = 1.f;
+#pragma unroll
+      for (int k = 0; k < FFA_CE_MAXK; ++k)
+        if (k == t) zt = z[k];
+      if (wt != 0.f) lsum += wt * (__logf(se) - __logf(zt));
+      if (pred) pred[i] = (uint8_t)am;
+      if (dlogits) {
+        const float c = wt * gs;
+#pragma unroll
+        for (int v = 0; v < MAXP; ++v) {
+          if (v < np) {
+            float o[EPP];
+#pragma unroll
+            for (int e = 0; e < EPP; ++e) {
+              const int k = v * EPP + e;
+              o[e] = (k < K) ? c * (z[k] * inv - (k == t ? 1.f : 0.f)) : 0.f;
+            }
+            uint4 u;
+            if constexpr (sizeof(T) == 2) {
+              u.x = ffa_pack_bf16x2(o[0], o[1]);
+              u.y = ffa_pack_bf16x2(o[2], o[3]);
+              u.z = ffa_pack_bf16x2(o[4], o[5]);
+              u.w = ffa_pack_bf16x2(o[6], o[7]);
+            } else {
+              u = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
+            }
+            *reinterpret_cast<uint4*>(mine + v * 16) = u;
+          }
+        }
+      }
+    }
+    if (dlogits) {
+      __syncthreads();
+      const long long base = ti * FFA_EW_THREADS;
+      const long long left = npix - base;
+      const int npc = (int)(left < FFA_EW_THREADS ? left : FFA_EW_THREADS) * np;
+      uint4* dst = reinterpret_cast<uint4*>(dlogits + base * Cp);
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k) {
+        const int idx = tid + FFA_EW_THREADS * k;
+        if (k < np && idx < npc) dst[idx] = *reinterpret_cast<const uint4*>(tile + loff[k]);
+      }
+    }
+    __syncthreads();  // the tile buffer is free for the next fill
+  }
+  lsum = ffa_wave_sum(lsum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int k = 0; k < FFA_EW_THREADS / 64; ++k) tot += red[k];
+    parts[blockIdx.x] = tot;
+  }
+}
+
 extern "C" long long ffa_softmax_ce_workspace_bytes(void) { return (long long)(2 * FFA_CE_BLOCKS + 4) * sizeof(float); }
 
 // loss[0] = weighted-mean CE; wsum_out[0] = sum of target weights; optional dlogits (scaled by
@@ -413,7 +565,18 @@ extern "C" int ffa_softmax_ce(int dtype, const void* logits, const uint8_t* targ
   hipLaunchKernelGGL(ce_weight_sum_kernel, dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream, targets, class_weights, K,
                      npix, parts_w);
   hipLaunchKernelGGL(ce_finalize_sum_kernel, dim3(1), dim3(64), 0, stream, parts_w, (int)nb, wsum_out);
-  if (dtype == FFA_BF16)
+  static const bool tiled = !(getenv("FFA_CE_TILED") && getenv("FFA_CE_TILED")[0] == '0');
+  const bool aligned = ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0;
+  if (tiled && aligned) {
+    if (dtype == FFA_BF16)
+      hipLaunchKernelGGL(softmax_ce_tiled_kernel<ffa_bf16>, dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream,
+                         (const ffa_bf16*)logits, targets, class_weights, wsum_out, grad_scale, (ffa_bf16*)dlogits, pred,
+                         parts_l, npix, K, Cp);
+    else
+      hipLaunchKernelGGL(softmax_ce_tiled_kernel<float>, dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream,
+                         (const float*)logits, targets, class_weights, wsum_out, grad_scale, (float*)dlogits, pred,
+                         parts_l, npix, K, Cp);
+  } else if (dtype == FFA_BF16)
     hipLaunchKernelGGL(softmax_ce_kernel<ffa_bf16>, dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream,
                        (const ffa_bf16*)logits, targets, class_weights, wsum_out, grad_scale, (ffa_bf16*)dlogits, pred,
                        parts_l, npix, K, Cp);
