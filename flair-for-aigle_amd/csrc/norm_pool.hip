@@ -1161,33 +1161,42 @@ maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, co
   for (unsigned j = threadIdx.x; j < (unsigned)W * CG; j += FFA_EW_THREADS) {
     const int ix = (int)(j / CG), g = (int)(j % CG);
     const long long i = row + j;
+    // The windows that contain input pixel (iy, ix): rows oy with iy = 2 oy - 1 + r -- one (r = 1) when iy is even, two
+    // (r = 0 and r = 2) when it is odd -- and the same for the columns: 1, 2 or 4 candidates.  All their index and
+    // gradient loads are issued before the first use (the branchy tap loop serialised up to nine dependent loads).
+    const int ny = (iy & 1) ? 2 : 1, nx = (ix & 1) ? 2 : 1;
+    const int oy_c[2] = {(iy & 1) ? (iy + 1) >> 1 : iy >> 1, (iy - 1) >> 1};
+    const int r_c[2] = {(iy & 1) ? 0 : 1, 2};
+    const int ox_c[2] = {(ix & 1) ? (ix + 1) >> 1 : ix >> 1, (ix - 1) >> 1};
+    const int s_c[2] = {(ix & 1) ? 0 : 1, 2};
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    if (add) ffa_load8<T>(add + i * 8, acc);  // a second gradient of the pooled tensor's input (U-Net skip), summed here
+    Raw8<T> addr, gr[4];
+    uint2 kk[4];
+    bool ok[4];
+    if (add) addr.load(add + i * 8);  // a second gradient of the pooled tensor's input (U-Net skip), summed here
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int ty = iy + 1 - r;
-      if (ty < 0 || (ty & 1)) continue;
-      const int oy = ty >> 1;
-      if (oy >= Ho) continue;
+    for (int c = 0; c < 4; ++c) {
+      const int cy = c >> 1, cx = c & 1;
+      ok[c] = cy < ny && cx < nx && oy_c[cy] >= 0 && oy_c[cy] < Ho && ox_c[cx] >= 0 && ox_c[cx] < Wo;
+      const long long o = ok[c] ? (((b * Ho + oy_c[cy]) * Wo + ox_c[cx]) * CG + g) * 8 : 0;
+      kk[c] = *reinterpret_cast<const uint2*>(idx + o);
+      gr[c].load(dy + o);
+    }
+    if (add) addr.get(acc);
+    // candidates in index order = taps ascending: the same order of additions as a loop over the nine taps
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int tx = ix + 1 - s;
-        if (tx < 0 || (tx & 1)) continue;
-        const int ox = tx >> 1;
-        if (ox >= Wo) continue;
-        const long long o = (((b * Ho + oy) * Wo + ox) * CG + g) * 8;
-        const uint2 k = *reinterpret_cast<const uint2*>(idx + o);
-        float gv[8];
-        ffa_load8<T>(dy + o, gv);
-        const int tap = r * 3 + s;
+    for (int c = 0; c < 4; ++c) {
+      if (!ok[c]) continue;
+      const int tap = r_c[c >> 1] * 3 + s_c[c & 1];
+      float gv[8];
+      gr[c].get(gv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const uint32_t word = e < 4 ? k.x : k.y;
-          const int w = (word >> (8 * (e & 3))) & 0xff;
-          if (w == tap) acc[e] += gv[e];
-        }
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t word = e < 4 ? kk[c].x : kk[c].y;
+        const int wq = (word >> (8 * (e & 3))) & 0xff;
+        if (wq == tap) acc[e] += gv[e];
       }
     }
     ffa_store8<T>(dx + i * 8, acc);
