@@ -158,13 +158,13 @@ class KernelTimer:
                 return
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             ev[0].record()
-            run_stage(1)  # channel_reduce_kernel<BnBwdOp> + the finalize kernel (a few microseconds)
+            run_stage(4)  # channel_reduce_kernel<BnBwdOp> alone
             ev[1].record()
+            run_stage(8)  # bn_bwd_finalize_kernel (per-channel vectors: no tensor traffic, not an HBM entry)
             ev[2].record()
             run_stage(2)  # bn_bwd_apply_kernel alone
             ev[3].record()
-            timer.hbm_records.append((f"channel_reduce_kernel<{dt},BnBwdOp>+finalize", nb * (3 if has_y else 2),
-                                      ev[0], ev[1]))
+            timer.hbm_records.append((f"channel_reduce_kernel<{dt},BnBwdOp>", nb * (3 if has_y else 2), ev[0], ev[1]))
             timer.hbm_records.append((f"bn_bwd_apply_kernel<{dt}>",
                                       nb * ((3 if has_y else 2) + 1 + (1 if has_dres else 0)), ev[2], ev[3]))
 
@@ -178,7 +178,7 @@ class KernelTimer:
             nb = logits.numel() * logits.element_size()
             dt = "bf16" if logits.dtype == torch.bfloat16 else "f32"
             # logits read + dlogits written (stored pitch), targets read + predictions written (1 B per pixel each)
-            timer.hbm_records.append((f"softmax_ce_kernel<{dt}>(+weight sum)", 2 * nb + 2 * targets.numel(), s, e))
+            timer.hbm_records.append((f"softmax_ce_tiled_kernel<{dt}>(+weight sum)", 2 * nb + 2 * targets.numel(), s, e))
             return r
 
         ops.bn_apply, ops.softmax_ce = bn_apply, softmax_ce
@@ -213,7 +213,12 @@ def pmc_traffic(symbol: str):
     if not found:
         return None
     kernels = json.load(open(found[-1]))["kernels"]  # the newest round's counter passes
-    mh = re.match(r"(bn_apply_kernel|bn_bwd_apply_kernel|softmax_ce_kernel)<(bf16|f32)>", symbol)
+    mh = re.match(r"(bn_apply_kernel|bn_bwd_apply_kernel|softmax_ce_kernel|softmax_ce_tiled_kernel)<(bf16|f32)>", symbol)
+    mc = re.match(r"channel_reduce_kernel<(bf16|f32),(BnBwdOp|StatOp)>", symbol)
+    if mc:
+        want = "void channel_reduce_kernel<{}, {}>".format("ffa_bf16" if mc.group(1) == "bf16" else "float", mc.group(2))
+        hit = [v for name, v in kernels.items() if name.startswith(want)]
+        return round(hit[0]["hbm_bytes_per_launch"]) if hit else None
     if mh:
         want = "void {}<{}>".format(mh.group(1), "ffa_bf16" if mh.group(2) == "bf16" else "float")
         hit = [v for name, v in kernels.items() if name.startswith(want)]

@@ -769,8 +769,9 @@ bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* 
 // when relu), saved mean/rstd.  Outputs: dx, dgamma, dbeta and -- when dres is non-null -- the gradient
 // of the residual branch (dy masked by the ReLU).
 // stages: bit 0 = reduction + finalize (dgamma, dbeta, apply coefficients into the workspace), bit 1 = apply (dx,
-// dres from the coefficients a stage-1 call left in the SAME workspace).  ffa_bn_bwd = both; the split exists so
-// that a profiler-free harness can bracket each kernel with its own events (bench.py's HBM roofline entry).
+// dres from the coefficients a stage-1 call left in the SAME workspace), bit 2 = the reduction alone, bit 3 = the
+// finalize alone (1 == 4 | 8).  ffa_bn_bwd = all; the split exists so that a profiler-free harness can bracket each
+// kernel with its own events (bench.py's HBM roofline entry).
 extern "C" int ffa_bn_bwd_stages(int dtype, const void* x, const void* dy, const void* y, const float* gamma,
                                  const float* beta, const float* mean, const float* rstd, void* dx, void* dres,
                                  float* dgamma, float* dbeta, long long npix, int C, int relu, void* workspace,
@@ -789,7 +790,7 @@ extern "C" int ffa_bn_bwd_stages(int dtype, const void* x, const void* dy, const
                                  const float* beta, const float* mean, const float* rstd, void* dx, void* dres,
                                  float* dgamma, float* dbeta, long long npix, int C, int relu, void* workspace,
                                  long long workspace_bytes, int stages, hipStream_t stream) {
-  FFA_REQUIRE(stages >= 1 && stages <= 3, "bn_bwd: stages must be 1, 2 or 3");
+  FFA_REQUIRE(stages >= 1 && stages <= 15, "bn_bwd: stages is a mask of 1 (reduce + finalize), 2 (apply), 4 (reduce), 8 (finalize)");
   FFA_REQUIRE(x && dy && dx && mean && rstd && dgamma && dbeta && workspace, "bn_bwd: null pointer");
   FFA_REQUIRE(relu >= 0 && relu <= 2, "bn_bwd: relu mode must be 0, 1 (mask from y) or 2 (mask from x)");
   FFA_REQUIRE(relu != 1 || y, "bn_bwd: relu mode 1 needs the forward output");
@@ -804,24 +805,24 @@ extern "C" int ffa_bn_bwd_stages(int dtype, const void* x, const void* dy, const
   const float inv_count = (float)(1.0 / (double)npix);
   float* coef = ws + (long long)FFA_MAX_PARTIALS * 2 * C;
   if (dtype == FFA_BF16) {
-    if (stages & 1) {
+    if (stages & 5)
       hipLaunchKernelGGL((channel_reduce_kernel<ffa_bf16, BnBwdOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
                          (const ffa_bf16*)x, (const ffa_bf16*)dy, (const ffa_bf16*)y, mean, rstd, gamma, beta, ws, npix,
                          C, relu);
+    if (stages & 9)
       hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ffa_cdiv(C, 8)), dim3(FFA_FIN_THREADS), 0, stream, ws, nb, C,
                          gamma, beta, mean, rstd, inv_count, dgamma, dbeta, coef);
-    }
     if (stages & 2)
       hipLaunchKernelGGL(bn_bwd_apply_kernel<ffa_bf16>, dim3(ew_grid_c(nvec, C)), dim3(FFA_EW_THREADS), 0, stream,
                          (const ffa_bf16*)x, (const ffa_bf16*)dy, (const ffa_bf16*)y, coef, (ffa_bf16*)dx,
                          (ffa_bf16*)dres, nvec, C, relu);
   } else {
-    if (stages & 1) {
+    if (stages & 5)
       hipLaunchKernelGGL((channel_reduce_kernel<float, BnBwdOp>), dim3(nb), dim3(FFA_EW_THREADS), 0, stream,
                          (const float*)x, (const float*)dy, (const float*)y, mean, rstd, gamma, beta, ws, npix, C, relu);
+    if (stages & 9)
       hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ffa_cdiv(C, 8)), dim3(FFA_FIN_THREADS), 0, stream, ws, nb, C,
                          gamma, beta, mean, rstd, inv_count, dgamma, dbeta, coef);
-    }
     if (stages & 2)
       hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid_c(nvec, C)), dim3(FFA_EW_THREADS), 0, stream,
                          (const float*)x, (const float*)dy, (const float*)y, coef, (float*)dx, (float*)dres, nvec, C,

@@ -295,8 +295,9 @@ int ffa_bn_apply(int dtype, const void* x, const void* residual, void* y, const 
 int ffa_bn_bwd(int dtype, const void* x, const void* dy, const void* y, const float* gamma, const float* beta,
                const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta, long long npix,
                int C, int relu, void* workspace, long long workspace_bytes, ffa_stream_t stream);
-/* ffa_bn_bwd in two calls: stages bit 0 = reduction + finalize (dgamma, dbeta and the apply coefficients, left in
- * the workspace), bit 1 = apply (dx, dres) from the coefficients of a stage-1 call on the SAME workspace; 3 = both.
+/* ffa_bn_bwd in separate calls: stages bit 0 = reduction + finalize (dgamma, dbeta and the apply coefficients, left in
+ * the workspace), bit 1 = apply (dx, dres) from the coefficients of an earlier call on the SAME workspace, bit 2 = the
+ * reduction kernel alone, bit 3 = the finalize kernel alone (1 == 4 | 8); 3 = everything.
  * Lets a harness bracket each kernel with its own events (bench.py's HBM roofline entry). */
 int ffa_bn_bwd_stages(int dtype, const void* x, const void* dy, const void* y, const float* gamma, const float* beta,
                       const float* mean, const float* rstd, void* dx, void* dres, float* dgamma, float* dbeta,
