@@ -565,7 +565,8 @@ extern "C" int ffa_softmax_ce(int dtype, const void* logits, const uint8_t* targ
   hipLaunchKernelGGL(ce_weight_sum_kernel, dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream, targets, class_weights, K,
                      npix, parts_w);
   hipLaunchKernelGGL(ce_finalize_sum_kernel, dim3(1), dim3(64), 0, stream, parts_w, (int)nb, wsum_out);
-  static const bool tiled = !(getenv("FFA_CE_TILED") && getenv("FFA_CE_TILED")[0] == '0');
+  const char* ct = getenv("FFA_CE_TILED");  // A/B switch, read per call (the tests flip it)
+  const bool tiled = !(ct && ct[0] == '0');
   const bool aligned = ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0;
   if (tiled && aligned) {
     if (dtype == FFA_BF16)

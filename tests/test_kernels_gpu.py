@@ -385,6 +385,55 @@ def test_softmax_ce_and_predictions(cuda, dtype):
         ops.predict_u8(zd, K, "logits")
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("K,pitch", [(5, 8), (12, 16), (19, 24), (19, 32), (23, 24), (32, 32)])
+@pytest.mark.parametrize("npix_shape", [(1, 7, 9), (2, 40, 56), (3, 16, 16)])
+def test_softmax_ce_tiled_kernel_equals_the_plain_kernel(cuda, dtype, K, pitch, npix_shape, monkeypatch):
+    """softmax_ce_tiled_kernel (tensor traffic staged through LDS in memory order) against softmax_ce_kernel (a thread
+    reads and writes its own pixel): same thread <-> pixel assignment and arithmetic, so loss, weight sum, gradient and
+    predictions are equal bit for bit -- every logits pitch, tiles of 63 / 4 480 / 768 pixels (partial, ragged, whole)"""
+    from flairhip import ops
+    B, H, W = npix_shape
+    g = torch.Generator().manual_seed(K * 100 + pitch + H)
+    z = (torch.randn(B, H, W, pitch, generator=g) * 3).to(dtype).to(cuda)
+    t = torch.randint(0, K, (B, H, W), generator=g).to(torch.uint8).to(cuda)
+    wts = (torch.rand(K, generator=g) * (torch.rand(K, generator=g) > 0.2)).to(cuda)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("FFA_CE_TILED", flag)
+        loss, wsum, dz, pred = ops.softmax_ce(z, t, wts, K, want_grad=True, want_pred=True)
+        torch.cuda.synchronize()
+        outs.append((loss.clone(), wsum.clone(), dz.clone(), pred.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    if pitch > K:
+        assert float(outs[1][2][..., K:].float().abs().max()) == 0.0  # pad channels of the gradient are written as zeros
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("H,W", [(21, 37), (8, 6), (64, 64)])
+def test_maxpool_backward_with_a_second_gradient_on_odd_sizes(cuda, dtype, H, W):
+    """maxpool_bwd_kernel enumerates the 1 / 2 / 4 windows of an input pixel directly: odd heights / widths (the last
+    row / column belongs to one window only), tiny maps, and the summed second gradient (the U-Net's skip path)"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(H * 7 + W)
+    B, C = 3, 24
+    x = torch.randn(B, C, H, W, generator=g).relu()
+    xq = rq(x, dtype).requires_grad_(True)
+    y_ref = F.max_pool2d(xq, 3, 2, 1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    add = torch.randn(B, C, H, W, generator=g)
+    y_ref.backward(rq(dy, dtype))
+    xd = to_nhwc(x, dtype, cuda, 24)
+    y, idx = ops.maxpool3x3s2_fwd(xd)
+    dx = ops.maxpool3x3s2_bwd(to_nhwc(dy, dtype, cuda, 24), idx, (H, W), add=to_nhwc(add, dtype, cuda, 24))
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(y, C), y_ref.detach())
+    want = xq.grad + rq(add, dtype)
+    lim = 1e-6 if dtype == torch.float32 else 2 ** -7 * float(want.abs().max())
+    assert (from_nhwc(dx, C) - want).abs().max().item() <= lim
+
+
 def test_onehot_to_index(cuda):
     from flairhip import ops
     g = torch.Generator().manual_seed(2)
