@@ -399,11 +399,15 @@ softmax_ce_kernel(const T* __restrict__ logits, const uint8_t* __restrict__ tgt,
 // place, and the gradient leaves LDS in memory order again.  The next tile's pieces are requested before the current
 // tile's arithmetic.  Thread <-> pixel assignment, the arithmetic and the order of the loss partial sums are those of
 // softmax_ce_kernel: results are bit-identical.
-template <typename T>
+// SUMS: the kernel also leaves, per block, the per-class sums of the gradient values it stores (as stored: rounded to
+// T) in parts_b[block][FFA_CE_MAXK] -- the bias gradient of the convolution that produced the logits is the column
+// sum of dlogits, otherwise a separate pass over the whole tensor (ffa_channel_sums: 537 MB at batch 32 x 512^2).
+template <typename T, bool SUMS>
 __global__ void __launch_bounds__(FFA_EW_THREADS)
 softmax_ce_tiled_kernel(const T* __restrict__ logits, const uint8_t* __restrict__ tgt, const float* __restrict__ w,
                         const float* __restrict__ wsum, const float* __restrict__ grad_scale, T* __restrict__ dlogits,
-                        uint8_t* __restrict__ pred, float* __restrict__ parts, long long npix, int K, int Cp) {
+                        uint8_t* __restrict__ pred, float* __restrict__ parts, float* __restrict__ parts_b,
+                        long long npix, int K, int Cp) {
   constexpr int EPP = 16 / (int)sizeof(T);   // elements per 16-byte piece
   constexpr int MAXP = FFA_CE_MAXK / EPP;    // pieces per pixel at the largest pitch: 4 (bf16) / 8 (f32)
   __shared__ __align__(16) unsigned char tile[FFA_EW_THREADS * (MAXP + 1) * 16];
@@ -411,6 +415,9 @@ softmax_ce_tiled_kernel(const T* __restrict__ logits, const uint8_t* __restrict_
   const int tid = threadIdx.x;
   const int np = Cp / EPP;   // pieces per pixel
   const int slots = np | 1;  // LDS pitch of a pixel in 16-byte slots: odd
+  float bsum[SUMS ? FFA_CE_MAXK : 1];
+#pragma unroll
+  for (int k = 0; k < (SUMS ? FFA_CE_MAXK : 1); ++k) bsum[k] = 0.f;
   float lsum = 0.f;
   float gs = 0.f;
   if (dlogits) gs = grad_scale[0] / wsum[0];
@@ -509,7 +516,21 @@ softmax_ce_tiled_kernel(const T* __restrict__ logits, const uint8_t* __restrict_
               u.y = ffa_pack_bf16x2(o[2], o[3]);
               u.z = ffa_pack_bf16x2(o[4], o[5]);
               u.w = ffa_pack_bf16x2(o[6], o[7]);
+              if constexpr (SUMS) {  // the values as the consumers of dlogits will read them
+                bsum[v * 8 + 0] += __uint_as_float(u.x << 16);
+                bsum[v * 8 + 1] += __uint_as_float(u.x & 0xffff0000u);
+                bsum[v * 8 + 2] += __uint_as_float(u.y << 16);
+                bsum[v * 8 + 3] += __uint_as_float(u.y & 0xffff0000u);
+                bsum[v * 8 + 4] += __uint_as_float(u.z << 16);
+                bsum[v * 8 + 5] += __uint_as_float(u.z & 0xffff0000u);
+                bsum[v * 8 + 6] += __uint_as_float(u.w << 16);
+                bsum[v * 8 + 7] += __uint_as_float(u.w & 0xffff0000u);
+              }
             } else {
+              if constexpr (SUMS) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bsum[v * 4 + e] += o[e];
+              }
               u = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
             }
             *reinterpret_cast<uint4*>(mine + v * 16) = u;
@@ -533,22 +554,74 @@ softmax_ce_tiled_kernel(const T* __restrict__ logits, const uint8_t* __restrict_
   }
   lsum = ffa_wave_sum(lsum);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+  if constexpr (SUMS) {  // per class: lanes of a wave (xor shuffles), then the four waves in order
+    float* wsums = reinterpret_cast<float*>(tile);  // the tile buffer is free after the loop's last barrier
+#pragma unroll
+    for (int k = 0; k < FFA_CE_MAXK; ++k) {
+      const float t = ffa_wave_sum(bsum[k]);
+      if ((threadIdx.x & 63) == 0) wsums[(threadIdx.x >> 6) * FFA_CE_MAXK + k] = t;
+    }
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     float tot = 0.f;
     for (int k = 0; k < FFA_EW_THREADS / 64; ++k) tot += red[k];
     parts[blockIdx.x] = tot;
   }
+  if constexpr (SUMS) {
+    if (threadIdx.x < FFA_CE_MAXK) {
+      const float* wsums = reinterpret_cast<const float*>(tile);
+      float t = 0.f;
+      for (int k = 0; k < FFA_EW_THREADS / 64; ++k) t += wsums[k * FFA_CE_MAXK + threadIdx.x];
+      parts_b[(size_t)blockIdx.x * FFA_CE_MAXK + threadIdx.x] = t;
+    }
+  }
 }
 
-extern "C" long long ffa_softmax_ce_workspace_bytes(void) { return (long long)(2 * FFA_CE_BLOCKS + 4) * sizeof(float); }
+// dlogit_sums[c] = fixed-order sum over the blocks' partial rows (eight lanes per class, each adding every eighth row
+// in double, then the eight lane sums in order)
+__global__ void __launch_bounds__(256) ce_finalize_cols_kernel(const float* __restrict__ parts_b, int nb, int Cp,
+                                                               float* __restrict__ out) {
+  __shared__ double sh[8][FFA_CE_MAXK];
+  const int k = threadIdx.x % FFA_CE_MAXK, l = threadIdx.x / FFA_CE_MAXK;
+  double s = 0.0;
+  for (int i = l; i < nb; i += 8) s += (double)parts_b[(size_t)i * FFA_CE_MAXK + k];
+  sh[l][k] = s;
+  __syncthreads();
+  if (l == 0 && k < Cp) {
+    double t = 0.0;
+    for (int j = 0; j < 8; ++j) t += sh[j][k];
+    out[k] = (float)t;
+  }
+}
+
+extern "C" long long ffa_softmax_ce_workspace_bytes(void) {
+  // block partials of the weight sum and of the loss, then [FFA_CE_BLOCKS][FFA_CE_MAXK] per-class gradient sums
+  return (long long)(2 * FFA_CE_BLOCKS + 4 + FFA_CE_BLOCKS * FFA_CE_MAXK) * sizeof(float);
+}
 
 // loss[0] = weighted-mean CE; wsum_out[0] = sum of target weights; optional dlogits (scaled by
 // grad_scale[0], a device scalar, default 1 when null is not allowed -> pass a device 1.0f) and pred.
+extern "C" int ffa_softmax_ce_sums(int dtype, const void* logits, const uint8_t* targets, const float* class_weights,
+                                   const float* grad_scale, float* loss, float* wsum_out, void* dlogits, uint8_t* pred,
+                                   float* dlogit_sums, long long npix, int K, int Cp, void* workspace,
+                                   long long workspace_bytes, hipStream_t stream);
+
 extern "C" int ffa_softmax_ce(int dtype, const void* logits, const uint8_t* targets, const float* class_weights,
                               const float* grad_scale, float* loss, float* wsum_out, void* dlogits, uint8_t* pred,
                               long long npix, int K, int Cp, void* workspace, long long workspace_bytes,
                               hipStream_t stream) {
+  return ffa_softmax_ce_sums(dtype, logits, targets, class_weights, grad_scale, loss, wsum_out, dlogits, pred, nullptr,
+                             npix, K, Cp, workspace, workspace_bytes, stream);
+}
+
+// ffa_softmax_ce that also returns dlogit_sums[Cp] = per-class sums over all pixels of the dlogits values it wrote (the
+// bias gradient of the layer that produced the logits, for the same upstream gradient of grad_scale[0]); needs dlogits
+// and 16-byte aligned tensors, FFA_ERR_UNSUPPORTED otherwise (callers then take ffa_channel_sums over dlogits).
+extern "C" int ffa_softmax_ce_sums(int dtype, const void* logits, const uint8_t* targets, const float* class_weights,
+                                   const float* grad_scale, float* loss, float* wsum_out, void* dlogits, uint8_t* pred,
+                                   float* dlogit_sums, long long npix, int K, int Cp, void* workspace,
+                                   long long workspace_bytes, hipStream_t stream) {
   FFA_REQUIRE(logits && targets && class_weights && loss && wsum_out && workspace, "softmax_ce: null pointer");
   FFA_REQUIRE(K >= 1 && K <= FFA_CE_MAXK && Cp % 8 == 0 && Cp >= K && Cp <= FFA_CE_MAXK,
               "softmax_ce: unsupported class count %d (pitch %d)", K, Cp);
@@ -568,15 +641,30 @@ extern "C" int ffa_softmax_ce(int dtype, const void* logits, const uint8_t* targ
   const char* ct = getenv("FFA_CE_TILED");  // A/B switch, read per call (the tests flip it)
   const bool tiled = !(ct && ct[0] == '0');
   const bool aligned = ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0;
-  if (tiled && aligned) {
+  float* parts_b = parts_l + FFA_CE_BLOCKS + 4;
+  if (dlogit_sums && !(tiled && aligned && dlogits)) {
+    ffa_set_error("softmax_ce_sums: needs dlogits, 16-byte aligned tensors and the tiled kernel");
+    return FFA_ERR_UNSUPPORTED;
+  }
+  if (tiled && aligned && dlogit_sums) {
     if (dtype == FFA_BF16)
-      hipLaunchKernelGGL(softmax_ce_tiled_kernel<ffa_bf16>, dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream,
+      hipLaunchKernelGGL((softmax_ce_tiled_kernel<ffa_bf16, true>), dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream,
                          (const ffa_bf16*)logits, targets, class_weights, wsum_out, grad_scale, (ffa_bf16*)dlogits, pred,
-                         parts_l, npix, K, Cp);
+                         parts_l, parts_b, npix, K, Cp);
     else
-      hipLaunchKernelGGL(softmax_ce_tiled_kernel<float>, dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream,
+      hipLaunchKernelGGL((softmax_ce_tiled_kernel<float, true>), dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream,
                          (const float*)logits, targets, class_weights, wsum_out, grad_scale, (float*)dlogits, pred,
-                         parts_l, npix, K, Cp);
+                         parts_l, parts_b, npix, K, Cp);
+    hipLaunchKernelGGL(ce_finalize_cols_kernel, dim3(1), dim3(256), 0, stream, parts_b, (int)nb, Cp, dlogit_sums);
+  } else if (tiled && aligned) {
+    if (dtype == FFA_BF16)
+      hipLaunchKernelGGL((softmax_ce_tiled_kernel<ffa_bf16, false>), dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream,
+                         (const ffa_bf16*)logits, targets, class_weights, wsum_out, grad_scale, (ffa_bf16*)dlogits, pred,
+                         parts_l, nullptr, npix, K, Cp);
+    else
+      hipLaunchKernelGGL((softmax_ce_tiled_kernel<float, false>), dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream,
+                         (const float*)logits, targets, class_weights, wsum_out, grad_scale, (float*)dlogits, pred,
+                         parts_l, nullptr, npix, K, Cp);
   } else if (dtype == FFA_BF16)
     hipLaunchKernelGGL(softmax_ce_kernel<ffa_bf16>, dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream,
                        (const ffa_bf16*)logits, targets, class_weights, wsum_out, grad_scale, (ffa_bf16*)dlogits, pred,

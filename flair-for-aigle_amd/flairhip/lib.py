@@ -127,6 +127,7 @@ SIGNATURES = {
     "ffa_bilinear_bwd": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _ll, _p]),
     "ffa_softmax_ce_workspace_bytes": (_ll, []),
     "ffa_softmax_ce": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p, _ll, _p]),
+    "ffa_softmax_ce_sums": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _i, _p, _ll, _p]),
     "ffa_scale_inplace": (_i, [_i, _p, _ll, _p, _p]),
     "ffa_predict_u8": (_i, [_i, _i, _p, _p] + [_i] * 9 + [_p]),
     "ffa_onehot_to_index": (_i, [_p, _p, _i, _i, _i, _i, _p]),

@@ -420,7 +420,9 @@ class _ConvBias(torch.autograd.Function):
                             conv.stride, conv.padding, out=_dw_out(conv)) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            s, _ = ops.channel_sums(dy)
+            s = _take_dlogit_sums(dy)  # the loss kernel summed its own gradient per class: no pass over dy
+            if s is None:
+                s, _ = ops.channel_sums(dy)
             db = s[: conv.out_channels].clone()
         return dx, dw, db, None
 
@@ -558,6 +560,20 @@ class _ToNHWC(torch.autograd.Function):
         return ops.nhwc_to_nchw(_as_nhwc_grad(dy), ctx.c), None, None
 
 
+# Per-class sums of the loss gradient, handed from the loss node to the node of the layer that produced the logits (its
+# bias gradient = the column sums of dlogits).  Keyed by the gradient buffer's address and geometry; an entry lives from
+# the loss node's backward to its consumer's backward within one backward pass (the buffer itself is alive in between)
+# and every loss forward clears what an unconsumed earlier pass may have left.
+_DLOGIT_SUMS = {}
+
+
+def _take_dlogit_sums(dy: torch.Tensor):
+    hit = _DLOGIT_SUMS.pop(dy.data_ptr(), None)
+    if hit is None or hit[0] != tuple(dy.shape) or hit[1] != dy.dtype or not dy.is_contiguous():
+        return None
+    return hit[2]
+
+
 class _SoftmaxCE(torch.autograd.Function):
     """Weighted-mean CE over NHWC logits.  When the logits need a gradient the forward pass writes dlogits too
     (for an upstream gradient of 1, in the same pass over the logits); backward multiplies them by the actual
@@ -567,12 +583,13 @@ class _SoftmaxCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, targets, weights, num_classes, holder):
         need = ctx.needs_input_grad[0]
-        loss, wsum, dlogits, pred = ops.softmax_ce(logits, targets, weights, num_classes, want_grad=need,
-                                                   want_pred=True)
+        _DLOGIT_SUMS.clear()  # nothing of an earlier backward pass may outlive the next loss evaluation
+        loss, wsum, dlogits, pred, sums = ops.softmax_ce(logits, targets, weights, num_classes, want_grad=need,
+                                                         want_pred=True, want_sums=True)
         if holder is not None:
             holder["pred"] = pred
             holder["wsum"] = wsum
-        ctx.dlogits = dlogits
+        ctx.dlogits, ctx.sums = dlogits, sums
         return loss.reshape(())
 
     @staticmethod
@@ -581,7 +598,11 @@ class _SoftmaxCE(torch.autograd.Function):
         if dlogits is None:
             raise RuntimeError("softmax-CE backward called twice (the fused gradient buffer was already consumed)")
         gs = g.detach().reshape(1).float().contiguous()
-        return ops.scale_inplace(dlogits, gs), None, None, None, None
+        sums, ctx.sums = ctx.sums, None
+        out = ops.scale_inplace(dlogits, gs)
+        if sums is not None:  # the sums belong to an upstream gradient of 1, like dlogits before the rescale
+            _DLOGIT_SUMS[out.data_ptr()] = (tuple(out.shape), out.dtype, sums * gs)
+        return out, None, None, None, None
 
 
 def conv_bn_act(x, conv: HipConv2d, bn: HipBatchNorm2d, relu: bool = True, residual=None):

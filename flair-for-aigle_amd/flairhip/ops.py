@@ -702,10 +702,13 @@ def bilinear_bwd(dy: torch.Tensor, in_hw: Tuple[int, int]) -> torch.Tensor:
 # loss / prediction
 
 def softmax_ce(logits: torch.Tensor, targets: torch.Tensor, class_weights: torch.Tensor, num_classes: int,
-               grad_scale: Optional[torch.Tensor] = None, want_grad: bool = False, want_pred: bool = False):
+               grad_scale: Optional[torch.Tensor] = None, want_grad: bool = False, want_pred: bool = False,
+               want_sums: bool = False):
     """Weighted-mean cross-entropy over NHWC logits [B,H,W,Cp] and uint8 targets [B,H,W].
 
-    -> (loss[1] f32, wsum[1] f32, dlogits or None, pred uint8 or None)
+    -> (loss[1] f32, wsum[1] f32, dlogits or None, pred uint8 or None); with want_sums (needs want_grad) a fifth value:
+    the per-class sums [Cp] f32 of dlogits over all pixels (the bias gradient of the layer that produced the logits),
+    or None where the library cannot take them in the same pass.
     """
     lib = _l.load()
     _chk_nhwc(logits, "logits")
@@ -722,9 +725,23 @@ def softmax_ce(logits: torch.Tensor, targets: torch.Tensor, class_weights: torch
     if want_grad and grad_scale is None:
         grad_scale = torch.ones(1, dtype=torch.float32, device=dev)
     ws = workspace(lib.ffa_softmax_ce_workspace_bytes(), dev, "ce")
+    if want_sums:
+        sums = torch.empty(cp, dtype=torch.float32, device=dev) if want_grad else None
+        rc = _l.ERR_UNSUPPORTED
+        if sums is not None:
+            rc = lib.ffa_softmax_ce_sums(_dt(logits), logits.data_ptr(), targets.data_ptr(), class_weights.data_ptr(),
+                                         _ptr(grad_scale), res[0:1].data_ptr(), res[1:2].data_ptr(), _ptr(dlogits),
+                                         _ptr(pred), sums.data_ptr(), npix, num_classes, cp, ws.data_ptr(), ws.numel(),
+                                         _stream())
+        if rc == 0:
+            return res[0:1], res[1:2], dlogits, pred, sums
+        if rc != _l.ERR_UNSUPPORTED:
+            _l.check(rc, "softmax_ce_sums")
     _l.check(lib.ffa_softmax_ce(_dt(logits), logits.data_ptr(), targets.data_ptr(), class_weights.data_ptr(),
                                 _ptr(grad_scale), res[0:1].data_ptr(), res[1:2].data_ptr(), _ptr(dlogits), _ptr(pred),
                                 npix, num_classes, cp, ws.data_ptr(), ws.numel(), _stream()), "softmax_ce")
+    if want_sums:
+        return res[0:1], res[1:2], dlogits, pred, None
     return res[0:1], res[1:2], dlogits, pred
 
 

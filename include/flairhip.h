@@ -362,6 +362,14 @@ long long ffa_softmax_ce_workspace_bytes(void);
 int ffa_softmax_ce(int dtype, const void* logits, const uint8_t* targets, const float* class_weights,
                    const float* grad_scale, float* loss, float* wsum_out, void* dlogits, uint8_t* pred,
                    long long npix, int K, int Cp, void* workspace, long long workspace_bytes, ffa_stream_t stream);
+/* ffa_softmax_ce that also returns dlogit_sums[Cp]: per class, the sum over all pixels of the dlogits values it wrote
+ * = the bias gradient of the convolution that produced the logits (torch: grad of segmentation_head.0.bias,
+ * flair_hub/models/checkpoint.py:226), taken in the same pass instead of a column-sum pass over dlogits.  Needs dlogits
+ * and 16-byte aligned tensors; FFA_ERR_UNSUPPORTED otherwise (then: ffa_channel_sums over dlogits). */
+int ffa_softmax_ce_sums(int dtype, const void* logits, const uint8_t* targets, const float* class_weights,
+                        const float* grad_scale, float* loss, float* wsum_out, void* dlogits, uint8_t* pred,
+                        float* dlogit_sums, long long npix, int K, int Cp, void* workspace, long long workspace_bytes,
+                        ffa_stream_t stream);
 
 /* x[0..n) *= scale[0] in place, scale a device scalar; a no-op pass when the scalar is exactly 1.  Used on the
  * dlogits ffa_softmax_ce wrote in the forward pass (for an upstream gradient of 1) when autograd hands the loss a

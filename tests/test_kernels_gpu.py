@@ -411,6 +411,33 @@ def test_softmax_ce_tiled_kernel_equals_the_plain_kernel(cuda, dtype, K, pitch, 
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("K,pitch,shape", [(19, 32, (2, 40, 56)), (12, 16, (1, 7, 9)), (23, 24, (3, 64, 64))])
+def test_softmax_ce_sums_are_the_column_sums_of_the_gradient_it_wrote(cuda, dtype, K, pitch, shape, monkeypatch):
+    """ffa_softmax_ce_sums: per-class sums of dlogits from the loss kernel itself (the head's bias gradient) against a
+    float64 column sum of the very tensor it wrote; everything else equal to ffa_softmax_ce bit for bit; refused
+    (-> None, the caller sums dlogits itself) when the tiled kernel is switched off"""
+    from flairhip import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(K + pitch + H)
+    z = (torch.randn(B, H, W, pitch, generator=g) * 3).to(dtype).to(cuda)
+    t = torch.randint(0, K, (B, H, W), generator=g).to(torch.uint8).to(cuda)
+    wts = (torch.rand(K, generator=g) + 0.1).to(cuda)
+    gs = torch.tensor([0.37], device=cuda)
+    base = ops.softmax_ce(z, t, wts, K, grad_scale=gs, want_grad=True, want_pred=True)
+    loss, wsum, dz, pred, sums = ops.softmax_ce(z, t, wts, K, grad_scale=gs, want_grad=True, want_pred=True,
+                                                want_sums=True)
+    torch.cuda.synchronize()
+    for a, b in zip(base, (loss, wsum, dz, pred)):
+        assert torch.equal(a, b)
+    want = dz.double().reshape(-1, pitch).sum(0)
+    assert sums is not None and sums.shape == (pitch,)
+    assert (sums.double() - want).abs().max().item() <= 1e-5 * max(1e-6, want.abs().max().item()) + 1e-9
+    monkeypatch.setenv("FFA_CE_TILED", "0")
+    assert ops.softmax_ce(z, t, wts, K, want_grad=True, want_sums=True)[4] is None
+    assert ops.softmax_ce(z, t, wts, K, want_grad=False, want_sums=True)[4] is None
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("H,W", [(21, 37), (8, 6), (64, 64)])
 def test_maxpool_backward_with_a_second_gradient_on_odd_sizes(cuda, dtype, H, W):
     """maxpool_bwd_kernel enumerates the 1 / 2 / 4 windows of an input pixel directly: odd heights / widths (the last

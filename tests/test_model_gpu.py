@@ -297,3 +297,32 @@ def test_fp32_training_trajectory_follows_the_oracle(cuda, fused):
     for k, (a, b) in enumerate(zip(got, ref)):
         # Adam normalises the update by |g|: sign-level differences in tiny gradients grow a little per step
         assert abs(a - b) <= (2e-5 if k == 0 else 2e-3) * abs(b), (k, got, ref)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("loss_scale", [1.0, 0.5])
+def test_head_bias_gradient_from_the_loss_kernel_equals_the_column_sum_pass(cuda, precision, loss_scale, monkeypatch):
+    """The segmentation head's bias gradient comes out of the loss kernel (per-class sums of the gradient it writes,
+    handed to the head's backward) instead of a pass over dlogits: same value as that pass (FFA_CE_TILED=0 disables the
+    hand-over), also when the loss is scaled before backward, and every other gradient is untouched bit for bit"""
+    from flairhip import nn as hnn
+    x, t = _inputs(2, 64, 96, seed=5)
+    grads = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FFA_CE_TILED", flag)
+        task, _, _ = make_pair(precision=precision)
+        task.train()
+        loss, _, _ = task.step({MOD: x.to(cuda), TASK: t.to(cuda)}, training=True)
+        (loss * loss_scale).backward()
+        torch.cuda.synchronize()
+        assert not hnn._DLOGIT_SUMS  # consumed by the head's backward (or never registered)
+        grads.append({k: p.grad.detach().float().cpu() for k, p in task.model.named_parameters() if p.grad is not None})
+    bias_key = [k for k in grads[0] if k.endswith("segmentation_head.0.bias")]
+    assert len(bias_key) == 1
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        if k == bias_key[0]:
+            assert (a - b).abs().max().item() <= 2e-5 * max(1e-6, b.abs().max().item())
+            assert b.abs().max().item() > 0
+        else:
+            assert torch.equal(a, b), k
