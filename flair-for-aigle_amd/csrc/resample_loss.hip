@@ -415,9 +415,11 @@ softmax_ce_tiled_kernel(const T* __restrict__ logits, const uint8_t* __restrict_
   const int tid = threadIdx.x;
   const int np = Cp / EPP;   // pieces per pixel
   const int slots = np | 1;  // LDS pitch of a pixel in 16-byte slots: odd
-  float bsum[SUMS ? FFA_CE_MAXK : 1];
+  // SUMS: FFA_EW_THREADS % np == 0 (the launcher checks), so every piece a thread moves out in the store phase holds
+  // the same EPP classes, (tid % np) * EPP ..: EPP running sums per thread
+  float bsum[SUMS ? EPP : 1];
 #pragma unroll
-  for (int k = 0; k < (SUMS ? FFA_CE_MAXK : 1); ++k) bsum[k] = 0.f;
+  for (int k = 0; k < (SUMS ? EPP : 1); ++k) bsum[k] = 0.f;
   float lsum = 0.f;
   float gs = 0.f;
   if (dlogits) gs = grad_scale[0] / wsum[0];
@@ -516,21 +518,7 @@ softmax_ce_tiled_kernel(const T* __restrict__ logits, const uint8_t* __restrict_
               u.y = ffa_pack_bf16x2(o[2], o[3]);
               u.z = ffa_pack_bf16x2(o[4], o[5]);
               u.w = ffa_pack_bf16x2(o[6], o[7]);
-              if constexpr (SUMS) {  // the values as the consumers of dlogits will read them
-                bsum[v * 8 + 0] += __uint_as_float(u.x << 16);
-                bsum[v * 8 + 1] += __uint_as_float(u.x & 0xffff0000u);
-                bsum[v * 8 + 2] += __uint_as_float(u.y << 16);
-                bsum[v * 8 + 3] += __uint_as_float(u.y & 0xffff0000u);
-                bsum[v * 8 + 4] += __uint_as_float(u.z << 16);
-                bsum[v * 8 + 5] += __uint_as_float(u.z & 0xffff0000u);
-                bsum[v * 8 + 6] += __uint_as_float(u.w << 16);
-                bsum[v * 8 + 7] += __uint_as_float(u.w & 0xffff0000u);
-              }
             } else {
-              if constexpr (SUMS) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bsum[v * 4 + e] += o[e];
-              }
               u = make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3]));
             }
             *reinterpret_cast<uint4*>(mine + v * 16) = u;
@@ -547,19 +535,44 @@ softmax_ce_tiled_kernel(const T* __restrict__ logits, const uint8_t* __restrict_
 #pragma unroll
       for (int k = 0; k < MAXP; ++k) {
         const int idx = tid + FFA_EW_THREADS * k;
-        if (k < np && idx < npc) dst[idx] = *reinterpret_cast<const uint4*>(tile + loff[k]);
+        if (k < np && idx < npc) {
+          const uint4 u = *reinterpret_cast<const uint4*>(tile + loff[k]);
+          dst[idx] = u;
+          if constexpr (SUMS) {  // the values as the consumers of dlogits will read them
+            if constexpr (sizeof(T) == 2) {
+              bsum[0] += __uint_as_float(u.x << 16);
+              bsum[1] += __uint_as_float(u.x & 0xffff0000u);
+              bsum[2] += __uint_as_float(u.y << 16);
+              bsum[3] += __uint_as_float(u.y & 0xffff0000u);
+              bsum[4] += __uint_as_float(u.z << 16);
+              bsum[5] += __uint_as_float(u.z & 0xffff0000u);
+              bsum[6] += __uint_as_float(u.w << 16);
+              bsum[7] += __uint_as_float(u.w & 0xffff0000u);
+            } else {
+              bsum[0] += __uint_as_float(u.x);
+              bsum[1] += __uint_as_float(u.y);
+              bsum[2] += __uint_as_float(u.z);
+              bsum[3] += __uint_as_float(u.w);
+            }
+          }
+        }
       }
     }
     __syncthreads();  // the tile buffer is free for the next fill
   }
   lsum = ffa_wave_sum(lsum);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
-  if constexpr (SUMS) {  // per class: lanes of a wave (xor shuffles), then the four waves in order
+  if constexpr (SUMS) {  // lanes l, l + np, l + 2 np, ... of a wave hold the same classes (np is a power of two <= 8)
     float* wsums = reinterpret_cast<float*>(tile);  // the tile buffer is free after the loop's last barrier
+    if (threadIdx.x < (FFA_EW_THREADS / 64) * FFA_CE_MAXK) wsums[threadIdx.x] = 0.f;  // classes beyond the pitch
+    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < FFA_CE_MAXK; ++k) {
-      const float t = ffa_wave_sum(bsum[k]);
-      if ((threadIdx.x & 63) == 0) wsums[(threadIdx.x >> 6) * FFA_CE_MAXK + k] = t;
+    for (int e = 0; e < EPP; ++e) {
+      float t = bsum[e];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+        if (o >= np) t += __shfl_xor(t, o, 64);
+      if ((threadIdx.x & 63) < np) wsums[(threadIdx.x >> 6) * FFA_CE_MAXK + (threadIdx.x & 63) * EPP + e] = t;
     }
   }
   __syncthreads();
@@ -578,19 +591,26 @@ softmax_ce_tiled_kernel(const T* __restrict__ logits, const uint8_t* __restrict_
   }
 }
 
-// dlogit_sums[c] = fixed-order sum over the blocks' partial rows (eight lanes per class, each adding every eighth row
-// in double, then the eight lane sums in order)
+// dlogit_sums[c] = fixed-order sum over the blocks' partial rows: one block per class, thread l adds rows l, l + 256,
+// ... in double (all loads in flight), thread 0 then adds the 256 thread sums in order
 __global__ void __launch_bounds__(256) ce_finalize_cols_kernel(const float* __restrict__ parts_b, int nb, int Cp,
                                                                float* __restrict__ out) {
-  __shared__ double sh[8][FFA_CE_MAXK];
-  const int k = threadIdx.x % FFA_CE_MAXK, l = threadIdx.x / FFA_CE_MAXK;
+  __shared__ double sh[256];
+  const int k = blockIdx.x;
+  float v[FFA_CE_BLOCKS / 256];
+#pragma unroll
+  for (int j = 0; j < FFA_CE_BLOCKS / 256; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    v[j] = i < nb ? parts_b[(size_t)i * FFA_CE_MAXK + k] : 0.f;
+  }
   double s = 0.0;
-  for (int i = l; i < nb; i += 8) s += (double)parts_b[(size_t)i * FFA_CE_MAXK + k];
-  sh[l][k] = s;
+#pragma unroll
+  for (int j = 0; j < FFA_CE_BLOCKS / 256; ++j) s += (double)v[j];
+  sh[threadIdx.x] = s;
   __syncthreads();
-  if (l == 0 && k < Cp) {
+  if (threadIdx.x == 0) {
     double t = 0.0;
-    for (int j = 0; j < 8; ++j) t += sh[j][k];
+    for (int j = 0; j < 256; ++j) t += sh[j];
     out[k] = (float)t;
   }
 }
@@ -642,8 +662,9 @@ extern "C" int ffa_softmax_ce_sums(int dtype, const void* logits, const uint8_t*
   const bool tiled = !(ct && ct[0] == '0');
   const bool aligned = ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0;
   float* parts_b = parts_l + FFA_CE_BLOCKS + 4;
-  if (dlogit_sums && !(tiled && aligned && dlogits)) {
-    ffa_set_error("softmax_ce_sums: needs dlogits, 16-byte aligned tensors and the tiled kernel");
+  const int pieces = Cp * (dtype == FFA_BF16 ? 2 : 4) / 16;  // 16-byte pieces per pixel
+  if (dlogit_sums && !(tiled && aligned && dlogits && FFA_EW_THREADS % pieces == 0)) {
+    ffa_set_error("softmax_ce_sums: needs dlogits, 16-byte aligned tensors, the tiled kernel and a pitch of 1, 2, 4 or 8 pieces");
     return FFA_ERR_UNSUPPORTED;
   }
   if (tiled && aligned && dlogit_sums) {
@@ -655,7 +676,7 @@ extern "C" int ffa_softmax_ce_sums(int dtype, const void* logits, const uint8_t*
       hipLaunchKernelGGL((softmax_ce_tiled_kernel<float, true>), dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream,
                          (const float*)logits, targets, class_weights, wsum_out, grad_scale, (float*)dlogits, pred,
                          parts_l, parts_b, npix, K, Cp);
-    hipLaunchKernelGGL(ce_finalize_cols_kernel, dim3(1), dim3(256), 0, stream, parts_b, (int)nb, Cp, dlogit_sums);
+    hipLaunchKernelGGL(ce_finalize_cols_kernel, dim3(Cp), dim3(256), 0, stream, parts_b, (int)nb, Cp, dlogit_sums);
   } else if (tiled && aligned) {
     if (dtype == FFA_BF16)
       hipLaunchKernelGGL((softmax_ce_tiled_kernel<ffa_bf16, false>), dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream,

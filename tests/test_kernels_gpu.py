@@ -430,8 +430,11 @@ def test_softmax_ce_sums_are_the_column_sums_of_the_gradient_it_wrote(cuda, dtyp
     for a, b in zip(base, (loss, wsum, dz, pred)):
         assert torch.equal(a, b)
     want = dz.double().reshape(-1, pitch).sum(0)
-    assert sums is not None and sums.shape == (pitch,)
-    assert (sums.double() - want).abs().max().item() <= 1e-5 * max(1e-6, want.abs().max().item()) + 1e-9
+    if pitch == 24:  # 3 (bf16) / 6 (f32) pieces per pixel do not divide the block: the library declines
+        assert sums is None
+    else:
+        assert sums is not None and sums.shape == (pitch,)
+        assert (sums.double() - want).abs().max().item() <= 1e-5 * max(1e-6, want.abs().max().item()) + 1e-9
     monkeypatch.setenv("FFA_CE_TILED", "0")
     assert ops.softmax_ce(z, t, wts, K, want_grad=True, want_sums=True)[4] is None
     assert ops.softmax_ce(z, t, wts, K, want_grad=False, want_sums=True)[4] is None
