@@ -878,12 +878,31 @@ extern "C" int ffa_onehot_to_index(const float* onehot, uint8_t* idx, int B, int
 
 __global__ void __launch_bounds__(FFA_EW_THREADS)
 confusion_kernel(const uint8_t* __restrict__ pred, const uint8_t* __restrict__ tgt, long long n, int K,
-                 unsigned long long* __restrict__ out) {
+                 unsigned long long* __restrict__ out, int vec16) {
   __shared__ unsigned int hist[FFA_CE_MAXK * FFA_CE_MAXK];
   const int bins = K * K;
   for (int i = threadIdx.x; i < bins; i += blockDim.x) hist[i] = 0;
   __syncthreads();
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+  const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long done = 0;
+  if (vec16) {  // both byte streams 16-byte aligned: 16 pixels per pair of loads (one byte per lane per load: 38 us)
+    const long long n16 = n / 16;
+    for (long long i = gid; i < n16; i += stride) {
+      const uint4 tv = reinterpret_cast<const uint4*>(tgt)[i];
+      const uint4 pv = reinterpret_cast<const uint4*>(pred)[i];
+      const uint32_t tq[4] = {tv.x, tv.y, tv.z, tv.w}, pq[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int t = (tq[j] >> (8 * b)) & 0xff, p = (pq[j] >> (8 * b)) & 0xff;
+          if (t < K && p < K) atomicAdd(&hist[t * K + p], 1u);
+        }
+    }
+    done = n16 * 16;
+  }
+  for (long long i = done + gid; i < n; i += stride) {
     const int t = tgt[i], p = pred[i];
     if (t < K && p < K) atomicAdd(&hist[t * K + p], 1u);
   }
@@ -898,7 +917,8 @@ extern "C" int ffa_confusion_matrix(const uint8_t* pred, const uint8_t* target, 
   long long nb = (n + FFA_EW_THREADS * 16 - 1) / (FFA_EW_THREADS * 16);
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
+  const int vec16 = ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target)) & 15) == 0 ? 1 : 0;
   hipLaunchKernelGGL(confusion_kernel, dim3((int)nb), dim3(FFA_EW_THREADS), 0, stream, pred, target, n, K,
-                     reinterpret_cast<unsigned long long*>(counts));
+                     reinterpret_cast<unsigned long long*>(counts), vec16);
   return ffa_check_launch("confusion_matrix");
 }

@@ -798,7 +798,7 @@ def test_confusion_matrix_kernel_and_jaccard_index(cuda):
     K = 19
     m = MulticlassJaccardIndex(K, average="macro").to(cuda)
     cm = np.zeros((K, K), np.int64)
-    for shape in ((2, 64, 96), (3, 40, 40), (1, 512, 512)):
+    for shape in ((2, 64, 96), (3, 40, 40), (1, 512, 512), (1, 37, 41), (1, 3, 5)):  # incl. ragged tails of the 16-pixel loads
         t = g.integers(0, 15, shape).astype(np.uint8)  # classes 15..18 never occur
         p = np.where(g.random(shape) < 0.7, t, g.integers(0, 17, shape)).astype(np.uint8)
         m.update(torch.from_numpy(p).to(cuda), torch.from_numpy(t).to(cuda))
