@@ -311,9 +311,7 @@ struct BnBwdOp {  // sum(g), sum(g * xhat) with g = dy masked by the ReLU
 // Streaming loops below keep FFA_EW_UNROLL independent 16-byte loads per operand in flight per thread (issued before
 // the first use) and consume them in index order: the sums are the same chains of additions as a plain loop.  With one
 // vector per iteration the wave waited out a full HBM round trip per 32 bytes (3.9 TB/s on the reduce at 4 waves/SIMD).
-#ifndef FFA_EW_UNROLL
-#define FFA_EW_UNROLL 4
-#endif
+// (FFA_EW_UNROLL is defined at the top of the file: the launch grids depend on it.)
 // FFA_EW_CHUNK 1: the U vectors of an iteration are consecutive 4 KB rows of one block (a block streams U * 4 KB
 // contiguous bytes per operand per iteration); 0: they are a grid stride apart
 #ifndef FFA_EW_CHUNK
