@@ -316,9 +316,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-symbol table to stderr")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of as one hipGraph replay")
-    ap.add_argument("--ddp-graph", action="store_true",
-                    help="N > 1: replay forward + backward as a hipGraph, then bucketed all-reduce + eager AdamW "
-                         "(default for N > 1: eager step, all-reduces from autograd hooks overlapped with backward)")
+    ap.add_argument("--ddp-graph", action="store_true", help="(default since round 3, kept for old command lines)")
+    ap.add_argument("--ddp-eager", action="store_true",
+                    help="N > 1: eager step with the all-reduces issued from autograd hooks (overlapped with backward) "
+                         "instead of the default graph(fwd+bwd) -> bucketed all-reduce -> graph(AdamW)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -344,7 +345,7 @@ def main():
 
     total_steps = args.steps + args.warmup
     cfg = unet_resnet34_config(in_channels=5, precision=args.precision, batch_size=args.batch,
-                               total_steps=total_steps + 16 + SETTLE_MAX_STEPS)  # + graph warm-up, settle, roofline pass
+                               total_steps=2 * total_steps + 16 + SETTLE_MAX_STEPS)  # + graph warm-up, settle, roofline pass
     torch.manual_seed(cfg["hyperparams"]["seed"])
     task = build_segmentation_module(cfg, {MOD: args.tile}, "train").to(dev)
     task.train()
@@ -365,16 +366,20 @@ def main():
         loss = task.training_step(batch, i)
         optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        sync.finish()
+        if sync._handles or world == 1:
+            sync.finish()  # all-reduces were issued from the autograd hooks, underneath backward
+        else:  # hook-less GradSync of the graph mode: hand the finished gradients over
+            ps = [p for p in task.model.parameters() if p.grad is not None]
+            sync.reduce_grads(ps, [p.grad for p in ps])
         optimizer.step()
         scheduler.step()
         return loss
 
     # single process: the whole step (forward, loss, metrics, backward, AdamW) is one hipGraph replay;
-    # multi process: eager, the RCCL all-reduces are issued from autograd hooks and overlap backward
-    # (flairhip.distributed); --ddp-graph: forward + backward replayed as a graph, then the bucketed all-reduce of the
-    # gradients and an eager AdamW step (collectives stay outside the graph, no overlap)
-    use_graph = (not args.no_graph) and (world == 1 or args.ddp_graph)
+    # multi process: THE SAME captured kernels as two graphs with the collectives between them -- graph(forward + loss +
+    # backward, weight gradients written into the flat buckets) -> bucketed RCCL all-reduce -> graph(AdamW)
+    # (flairhip.graph.GraphedTrainStep); --ddp-eager: eager step, all-reduces from autograd hooks, overlapped with backward
+    use_graph = (not args.no_graph) and (world == 1 or not args.ddp_eager)
     graphed = None
     if use_graph:
         from flairhip.graph import GraphedTrainStep
@@ -452,10 +457,22 @@ def main():
     torch.cuda.synchronize()
     timer.enabled = False
     loss = final_loss_t
+    # the same K steps run eagerly (launch by launch, uninstrumented): a multi-GPU value must be compared with the
+    # one-GPU value of the SAME step mode, so both are in every line
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eager_step(args.warmup + args.steps + roof_steps + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed_eager = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed, elapsed_eager], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, elapsed_eager = float(tt[0].item()), float(tt[1].item())
 
     final_loss = float(loss.item())
     if rank == 0:
@@ -486,6 +503,9 @@ def main():
                                    f"train step (BASELINE.json configs[{1 if world == 1 else 2}])",
                        "global_batch": B * world, "tile": S, "parallelism": f"dp{world}"},
             "final_loss": round(final_loss, 5), "hip_graph": bool(use_graph),
+            "step_mode": ("hipgraph(whole step)" if world == 1 else "hipgraph(fwd+bwd) -> bucketed all-reduce -> hipgraph(adamw)")
+                         if use_graph else ("eager" if world == 1 else "eager, all-reduce from autograd hooks"),
+            "ms_per_step_eager": round(elapsed_eager / args.steps * 1e3, 3),
             "roofline": roofline,
         }
         hsum = timer.hbm_summary()

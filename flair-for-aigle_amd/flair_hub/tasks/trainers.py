@@ -79,8 +79,9 @@ class HipTrainer:
             raise RuntimeError("HipTrainer drives the MI355X path only (accelerator='gpu'); the CPU restatement "
                                "lives in oracle/ and is test infrastructure")
         self.max_epochs, self.max_steps = max_epochs, max_steps
-        # single process only: forward + loss + backward + optimizer captured once and replayed per batch
-        # (flairhip.graph.GraphedTrainStep); batches of another shape and modality dropout fall back to eager steps
+        # forward + loss + backward + optimizer captured once and replayed per batch (flairhip.graph.GraphedTrainStep;
+        # several ranks: graph(forward + backward) -> bucketed all-reduce -> graph(optimizer)); batches of another
+        # shape and modality dropout fall back to eager steps
         self.hip_graph = bool(hip_graph)
         self.default_root_dir = default_root_dir
         self.monitor, self.monitor_mode = monitor, monitor_mode
@@ -132,12 +133,20 @@ class HipTrainer:
         interval = sched_cfg.get("interval", "epoch") if sched_cfg else None
         model._lr_scheduler = scheduler
         self.optimizers = [optimizer]
-        sync = GradSync(model)
+        use_graph = (self.hip_graph and not getattr(model, "mod_dropout", False) and
+                     isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)))
+        graph_ddp = use_graph and self.world_size > 1
+        # exact_unused: a parameter no rank produced a gradient for keeps grad = None, as under the reference's
+        # ddp_find_unused_parameters_true and as in the single-GPU path (AdamW then skips it instead of decaying it);
+        # graph mode runs without autograd hooks: the finished gradients are handed to reduce_grads()
+        sync = GradSync(model, hooks=not graph_ddp, exact_unused=True)
+
+        def reduce_now():
+            ps = [p for p in model.parameters() if p.grad is not None]
+            sync.reduce_grads(ps, [p.grad for p in ps])
 
         best = None
         done = False
-        use_graph = (self.hip_graph and self.world_size == 1 and not getattr(model, "mod_dropout", False) and
-                     isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)))
         graphed, graph_sig, loss = None, None, None
         for epoch in range(self.max_epochs):
             model.train()
@@ -152,7 +161,7 @@ class HipTrainer:
                     # to the stream they were created on, and running them from the capture stream aborts the capture
                     loss = None
                     graphed = GraphedTrainStep(model, optimizer, {k: v for k, v in batch.items() if torch.is_tensor(v)},
-                                               warmup_steps=0)
+                                               warmup_steps=0, grad_reduce=sync.reduce_grads if graph_ddp else None)
                     graph_sig = {k: (tuple(v.shape), v.dtype) for k, v in batch.items() if torch.is_tensor(v)}
                 if graphed is not None and graph_sig == {k: (tuple(v.shape), v.dtype) for k, v in batch.items()
                                                          if torch.is_tensor(v)}:
@@ -161,7 +170,10 @@ class HipTrainer:
                     loss = model.training_step(batch, i)
                     optimizer.zero_grad(set_to_none=True)
                     loss.backward()
-                    sync.finish()
+                    if graph_ddp:
+                        reduce_now()
+                    else:
+                        sync.finish()
                     optimizer.step()
                 if scheduler is not None and interval == "step":
                     scheduler.step()

@@ -148,9 +148,17 @@ class Jp2Raster(RasterBase):
                 wf["epsg"] = (geo or {}).get("epsg")
                 geo = wf
         from PIL import Image
-        with Image.open(path) as im:  # header only: size and mode, nothing is decoded here
-            self.width, self.height = im.size
-            mode = im.mode
+        # header only: size and mode, nothing is decoded here.  Pillow checks the pixel count against
+        # MAX_IMAGE_PIXELS (~179 MP) inside Image.open and raises DecompressionBombError above twice that: a 25 000 x
+        # 25 000 BD ORTHO mosaic is 625 MP, so the guard is lifted around the header read as it is around the decode
+        keep = Image.MAX_IMAGE_PIXELS
+        Image.MAX_IMAGE_PIXELS = None
+        try:
+            with Image.open(path) as im:
+                self.width, self.height = im.size
+                mode = im.mode
+        finally:
+            Image.MAX_IMAGE_PIXELS = keep
         try:
             self.count, self.dtype = {"L": (1, np.uint8), "LA": (2, np.uint8), "RGB": (3, np.uint8),
                                       "RGBA": (4, np.uint8), "I;16": (1, np.uint16), "I;16L": (1, np.uint16),

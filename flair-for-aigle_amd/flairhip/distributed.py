@@ -66,6 +66,7 @@ class GradSync:
         self.always_sync = always_sync
         self.exact_unused = exact_unused
         self._flags: Optional[torch.Tensor] = None
+        self._given_key, self._given_any = None, None  # reduce_grads: cached 'some rank has a gradient' mask
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params: List[torch.nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
         self._index = {p: i for i, p in enumerate(self.params)}
@@ -209,8 +210,16 @@ class GradSync:
     def reduce_grads(self, params, grads) -> None:
         """Mean over ranks of ``grads`` (one tensor per parameter of ``params``, e.g. the static gradient tensors of a
         replayed hipGraph), through the same flat buckets: copy in (a no-op for gradients that already live in their
-        bucket view), one all-reduce per bucket (all in flight before the first wait), scale, and point every
-        ``p.grad`` at its bucket view for the optimizer."""
+        bucket view), one all-reduce per bucket, scale, and point every ``p.grad`` at its bucket view for the optimizer.
+
+        RCCL runs the bucket collectives in issue order on its own stream, so all of them are launched before the first
+        wait (the compute stream waits stream-side, the host never blocks).  gloo (CPU rehearsals, several ranks sharing
+        one GPU) stages device tensors through host buffers in worker threads; three 32 MiB collectives in flight at
+        once made its ranks interleave segments and took 0.5-15 s per step on a GPU box (round 2's "13 s/step",
+        tools/ddp_graph_probe.py), so there each bucket is finished before the next is started.
+
+        ``exact_unused``: parameters outside ``params`` keep ``grad = None`` unless another rank handed one in (the set
+        is exchanged once per distinct ``params`` set, not per step: under a replayed graph it never changes)."""
         if self._buckets is None:
             self._build_buckets([self._index[p] for p in params])
         given = set()
@@ -223,14 +232,34 @@ class GradSync:
             for p, off in b.slots:
                 if p not in given:
                     b.flat[off: off + p.numel()].zero_()
-        if self.world > 1:
-            works = [dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                     for b in self._buckets]
+        if self.world > 1 or self.always_sync:
+            serial = dist.get_backend(self.group) == "gloo"
+            works = []
+            for b in self._buckets:
+                w = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if serial:
+                    w.wait()
+                works.append(w)
             for b, w in zip(self._buckets, works):
-                w.wait()
+                if not serial:
+                    w.wait()
                 b.flat.mul_(1.0 / self.world)
+        somewhere = None
+        if self.exact_unused and len(given) < len(self.params):
+            key = frozenset(self._index[p] for p in given)
+            if self._given_key != key:
+                flags = torch.zeros(len(self.params), dtype=torch.float32, device=self.params[0].device)
+                if given:
+                    flags[torch.tensor(sorted(key), device=flags.device)] = 1.0
+                if self.world > 1 or self.always_sync:
+                    dist.all_reduce(flags, op=dist.ReduceOp.SUM, group=self.group)
+                self._given_key, self._given_any = key, [v > 0 for v in flags.tolist()]
+            somewhere = self._given_any
         for p in self.params:
-            p.grad = self._view(p)
+            if somewhere is None or somewhere[self._index[p]]:
+                p.grad = self._view(p)
+            elif p not in given:
+                p.grad = None
 
     def remove(self) -> None:
         for h in self._handles:

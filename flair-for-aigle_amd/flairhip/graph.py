@@ -13,9 +13,11 @@ graph alive (a stored loss) keep its AccumulateGrad nodes alive, and those run o
 from inside the capture that is an illegal cross-stream dependency.  Drop such references before constructing a
 GraphedTrainStep (HipTrainer does; the warm-up steps here never keep their loss).
 
-With world size > 1 either the step runs eagerly with the gradient all-reduces issued from autograd hooks
-(flairhip.distributed.GradSync, overlapped with backward), or -- ``grad_reduce`` -- forward + backward are replayed
-as a graph and followed by the bucketed all-reduce and an eager optimizer step (collectives outside the graph).
+With world size > 1 (``grad_reduce``) the same captured kernels run as TWO graphs with the collectives between them:
+graph A = forward + loss + backward (weight gradients written straight into GradSync's flat buckets), then the bucketed
+all-reduce (RCCL, eager calls on RCCL's stream, the compute stream waits for them stream-side), then graph B = the
+optimizer step.  One rank and several ranks therefore execute the same kernels from the same captures; the eager step
+with the all-reduces issued from autograd hooks (overlapped with backward) stays available as the fallback.
 """
 from __future__ import annotations
 
@@ -42,8 +44,8 @@ class GraphedTrainStep:
     """step(batch) -> loss tensor (static buffer, valid until the next call).
 
     ``grad_reduce(params, grads)`` (e.g. flairhip.distributed.GradSync(hooks=False).reduce_grads) switches to the
-    data-parallel form: only forward + loss + backward are captured, every replay is followed by the gradient
-    reduction and an eager ``optimizer.step()`` -- collectives stay outside the graph."""
+    data-parallel form: forward + loss + backward are one graph, the optimizer step a second one, and every replay of
+    the first is followed by the gradient reduction -- collectives stay outside the captures."""
 
     def __init__(self, task, optimizer: torch.optim.Optimizer, example_batch: Dict[str, torch.Tensor],
                  warmup_steps: int = 3, after_step: Optional[Callable[[], None]] = None,
@@ -51,8 +53,7 @@ class GraphedTrainStep:
         self.task, self.optimizer, self.after_step, self.grad_reduce = task, optimizer, after_step, grad_reduce
         self.static_batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
         self._bns = [m for m in task.modules() if isinstance(m, hnn.HipBatchNorm2d)]
-        if grad_reduce is None:
-            make_capturable(optimizer)
+        make_capturable(optimizer)
 
         # warm-up on a side stream: sizes every workspace, fills the weight-pack plan, creates optimizer state
         side = torch.cuda.Stream()
@@ -78,9 +79,17 @@ class GraphedTrainStep:
         self.loss = loss
         for bn, n in zip(self._bns, pending):  # capture ran the Python but not the kernels
             bn._pending_batches = n
+        self.opt_graph = None
         if grad_reduce is not None:  # the gradient tensors the replay rewrites in place
             self.params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
             self.static_grads = [p.grad for p in self.params]
+            # point every p.grad at its bucket view (the reduction runs on whatever the capture left in the gradient
+            # buffers -- no kernel of graph A has run yet, the values are never used) and capture the optimizer step on
+            # those tensors: the same addresses in every later step
+            grad_reduce(self.params, self.static_grads)
+            self.opt_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.opt_graph):
+                optimizer.step()
 
     def _eager_step(self, i: int):
         loss = self.task.training_step(self.static_batch, i)
@@ -106,7 +115,8 @@ class GraphedTrainStep:
         hnn.bump_state_epoch()
         if self.grad_reduce is not None:
             self.grad_reduce(self.params, self.static_grads)
-            self.optimizer.step()
+            self.opt_graph.replay()
+            hnn.bump_state_epoch()
         for bn in self._bns:  # host-side bookkeeping the replay skips
             bn.note_batch()
         if self.after_step is not None:

@@ -217,3 +217,51 @@ def test_sharded_loader_covers_the_data_once():
                 assert len(b["ids"]) == b["x"].numel() and b["meta"] == 1
                 got += b["x"].tolist()
         assert sorted(got) == list(range(want))
+
+
+# --------------------------------------------------------------------------------------------------
+# the hook-less protocol of the hipGraph data-parallel step (GraphedTrainStep(grad_reduce=GradSync.reduce_grads)):
+# finished gradients are handed over after backward; with exact_unused a parameter that no rank produced a gradient
+# for keeps grad = None, so AdamW neither decays it nor creates state for it (the reference's
+# ddp_find_unused_parameters_true behaviour, flair_hub/tasks/trainers.py:81-91)
+
+
+def _reduce_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "flair-for-aigle_amd"))
+    from flairhip.distributed import GradSync
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(77 + rank)
+    net = Net()
+    sync = GradSync(net, bucket_bytes=100 * 1024, hooks=False, exact_unused=True)
+    unused0 = net.unused.weight.detach().clone()  # after the broadcast from rank 0
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-2, weight_decay=0.1)
+    for step in range(4):
+        x, y = _data(rank, step)
+        loss = ((net(x) - y) ** 2).mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        ps = [p for p in net.parameters() if p.grad is not None]
+        sync.reduce_grads(ps, [p.grad for p in ps])
+        assert net.unused.weight.grad is None and net.unused.bias.grad is None
+        if step == 3:
+            torch.save({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None},
+                       os.path.join(out_dir, f"rgrads_{rank}.pt"))
+        opt.step()
+    assert torch.equal(net.unused.weight, unused0), "AdamW touched a parameter nobody produced a gradient for"
+    assert net.unused.weight not in opt.state
+    torch.save(net.state_dict(), os.path.join(out_dir, f"rweights_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_reduce_grads_hookless_protocol_leaves_unused_parameters_alone(tmp_path):
+    world = 2
+    mp.spawn(_reduce_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    w0, w1 = (torch.load(tmp_path / f"rweights_{r}.pt") for r in range(world))
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), f"replicas diverged at {k}"
+    g0, g1 = (torch.load(tmp_path / f"rgrads_{r}.pt") for r in range(world))
+    assert set(g0) == set(g1) and not any(k.startswith("unused") for k in g0)
+    # mean of the per-rank gradients at the common weights of step 3 is what both ranks hold
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k

@@ -144,3 +144,21 @@ def test_prep_config_picks_the_jp2_of_an_images_folder(tmp_path):
     assert cfg["image_bounds"] is not None and cfg["output_path"] == str(tmp_path / "out")
     with pytest.raises(FileNotFoundError, match="no raster"):
         prep_config(*args, images_folder=str(tmp_path / "log"))
+
+
+def test_mosaics_beyond_pillows_pixel_guard_open_and_decode(tmp_path, monkeypatch):
+    """A 25 000 x 25 000 BD ORTHO tile is 625 MP, 3.5x Pillow's MAX_IMAGE_PIXELS; Image.open itself raises
+    DecompressionBombError above twice the limit.  Shrink the limit instead of growing the file: a 70 x 93 image is
+    then "too large" in exactly the same way, in the constructor (header read) and in the decode."""
+    from PIL import Image
+    monkeypatch.setattr(Image, "MAX_IMAGE_PIXELS", 1000)
+    g = np.random.default_rng(5)
+    arr = g.integers(0, 255, (70, 93)).astype(np.uint8)
+    p = str(tmp_path / "big.jp2")
+    Image.fromarray(arr).save(p, format="JPEG2000", irreversible=False)
+    with pytest.raises(Image.DecompressionBombError):
+        Image.open(p)
+    with open_raster(p) as r:
+        assert (r.height, r.width) == arr.shape
+        assert np.array_equal(r.read(1), arr)
+    assert Image.MAX_IMAGE_PIXELS == 1000  # restored after both steps

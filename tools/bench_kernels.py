@@ -124,9 +124,33 @@ def bench_bn(args):
         print(f"{name:10s} {kname:10s} {us:9.1f} {nbytes / us / 1e3:9.0f}")
 
 
+def bench_blas(args):
+    """The equal-FLOP GEMM of every MFMA-bound conv shape (M = B*Ho*Wo pixels, N = Cout, K = Cin*k*k) through torch's
+    matmul = hipBLASLt on this image, same box, random bf16 operands: what a tuned vendor GEMM reaches on these M/N/K,
+    i.e. the ceiling the implicit-GEMM kernels are measured against (an im2col-free conv moves 1/9 of the A bytes, so
+    it can be faster, but not by the MFMA schedule)."""
+    dev = torch.device("cuda:0")
+    dt = torch.bfloat16
+    print(f"{'shape':10s} {'M':>8s} {'N':>5s} {'K':>6s} {'us':>9s} {'TFLOP/s':>9s}   layout")
+    for name, cin, cout, k, stride, pad, H in CONV_SHAPES:
+        if args.only and args.only != name:
+            continue
+        if cout < 64 or k != 3 or stride != 1:
+            continue
+        Ho = (H + 2 * pad - k) // stride + 1
+        M, N, K = B * Ho * Ho, cout, cin * k * k
+        a = torch.randn(M, K, device=dev).to(dt)
+        w = torch.randn(N, K, device=dev).to(dt)
+        wt = w.t().contiguous()
+        for lay, fn in (("a[M,K] @ w[N,K]^T", lambda: torch.matmul(a, w.t())), ("a[M,K] @ w[K,N]", lambda: torch.matmul(a, wt))):
+            us = timeit(fn, iters=args.iters)
+            print(f"{name:10s} {M:8d} {N:5d} {K:6d} {us:9.1f} {2.0 * M * N * K / us / 1e6:9.1f}   {lay}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
+    ap.add_argument("--blas", action="store_true", help="hipBLASLt (torch.matmul) on the equal-FLOP GEMM of each MFMA-bound conv shape")
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--bn", action="store_true", help="BatchNorm kernels instead of the convolutions")
@@ -136,6 +160,8 @@ def main():
     args = ap.parse_args()
     if args.bn:
         return bench_bn(args)
+    if args.blas:
+        return bench_blas(args)
     dev = torch.device("cuda:0")
     dt = torch.bfloat16
     kinds = args.kinds.split(",")
