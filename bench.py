@@ -75,8 +75,9 @@ class KernelTimer:
             flops = 2.0 * B * (Ho * Wo / (dil * dil)) * w.rows_real * w.ch_real * w.kh * w.kw
             tile = "8x32" if Wo >= 32 else "16x16"
             dt = "bf16" if x.dtype == torch.bfloat16 else "f32"
-            if w.bco & 0x1000:  # ring-layout operand (FFA_RING=1): conv3x3_ring_kernel
-                sym = f"conv3x3_ring_kernel<{dt},{tile}{_hk_tag(w, x.dtype)}>"
+            if w.bco & 0x1000:  # ring-layout operand: conv3x3_ring16_kernel (bf16, the default) / conv3x3_ring_kernel (f32)
+                sym = (f"conv3x3_ring16_kernel<bf16,co64,{tile}>" if dt == "bf16"
+                       else f"conv3x3_ring_kernel<{dt},{tile}{_hk_tag(w, x.dtype)}>")
             elif ops.conv_is_persistent(x.dtype, B, Ho, Wo, w, dil):  # blocks walking several tiles: its own symbol
                 sym = f"conv3x3_persist_kernel<{dt},bco{w.bco},{tile}{_hk_tag(w, x.dtype)}>"
             else:
@@ -223,6 +224,11 @@ def pmc_traffic(symbol: str):
         want = "void {}<{}>".format(mh.group(1), "ffa_bf16" if mh.group(2) == "bf16" else "float")
         hit = [v for name, v in kernels.items() if name.startswith(want)]
         return round(hit[0]["hbm_bytes_per_launch"]) if hit else None
+    m16 = re.match(r"conv3x3_ring16_kernel<bf16,co64,(\d+)x(\d+)>", symbol)
+    if m16:  # template arguments <WCO, WPX, NT, TH, TW, OCC, PRO>
+        want = "void conv3x3_ring16_kernel<1, 4, 4, {}, {}, ".format(*m16.group(1, 2))
+        hit = [v for name, v in kernels.items() if name.startswith(want)]
+        return round(max(hit, key=lambda v: v["launches"])["hbm_bytes_per_launch"]) if hit else None
     mr = re.match(r"conv3x3_ring_kernel<(bf16|f32),(\d+)x(\d+)", symbol)
     if mr:
         want = "void conv3x3_ring_kernel<{}, ".format("ffa_bf16" if mr.group(1) == "bf16" else "float")
@@ -314,6 +320,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--tile", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the short BASELINE configs[3] / configs[4] measurements appended to the line (N = 1 only)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-symbol table to stderr")
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of as one hipGraph replay")
     ap.add_argument("--ddp-graph", action="store_true", help="(default since round 3, kept for old command lines)")
@@ -510,21 +518,47 @@ def main():
         }
         hsum = timer.hbm_summary()
         if hsum:
+            # the HBM-bound group of the step, TIME-WEIGHTED: every bracketed streaming kernel (BatchNorm apply /
+            # backward reduce / backward apply, loss) -- algorithmic bytes of all their launches over their summed
+            # duration; the per-symbol rates sit beside it (the best symbol alone flattered the group in round 2)
+            tb = sum(v["bytes"] for v in hsum.values())
+            ts = sum(v["seconds"] for v in hsum.values())
+            gbs = tb / ts / 1e9
             hd = max(hsum.items(), key=lambda kv: kv[1]["seconds"])
-            gbs = hd[1]["bytes"] / hd[1]["seconds"] / 1e9
             out["roofline_hbm"] = {
-                "bound": "hbm", "kernel": hd[0], "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(gbs / 8000.0, 4), "peak_measured_copy": 6290.0,
-                "frac_of_measured_copy": round(gbs / 6290.0, 4), "traffic": pmc_traffic(hd[0]),
-                "launches_per_step": hd[1]["launches"] / roof_steps,
-                "avg_launch_ms": round(hd[1]["seconds"] / hd[1]["launches"] * 1e3, 4),
-                "algorithmic_bytes_per_launch": round(hd[1]["bytes"] / hd[1]["launches"]),
-                "hbm_kernels_share_of_step": round(sum(v["seconds"] for v in hsum.values()) *
-                                                   (args.steps / roof_steps) / elapsed, 4)}
+                "bound": "hbm", "kernel": "time-weighted: " + " + ".join(sorted(hsum)), "achieved": round(gbs, 1),
+                "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "peak_measured_copy": 6290.0,
+                "frac_of_measured_copy": round(gbs / 6290.0, 4),
+                "traffic": pmc_traffic(hd[0]), "traffic_kernel": hd[0],
+                "launches_per_step": sum(v["launches"] for v in hsum.values()) / roof_steps,
+                "algorithmic_bytes_per_step": round(tb / roof_steps),
+                "per_kernel_GBps": {k: round(v["bytes"] / v["seconds"] / 1e9, 1) for k, v in sorted(hsum.items())},
+                "hbm_kernels_share_of_step": round(ts * (args.steps / roof_steps) / elapsed, 4)}
             if args.breakdown:
                 for k, v in sorted(hsum.items(), key=lambda kv: -kv[1]["seconds"]):
                     print(f"  {k:62s} {v['seconds'] / roof_steps * 1e3:8.3f} ms/step {v['launches'] // roof_steps:4d} "
                           f"launches {v['bytes'] / v['seconds'] / 1e9:8.0f} GB/s", file=sys.stderr)
+        if world == 1 and not args.no_extras:
+            # BASELINE.json configs[3] (Swin-T + UPerNet, 512 x 512, batch 32) and configs[4]'s per-GPU work (aerial +
+            # DEM + Sentinel-2 series, COSIA + LPIS heads, batch 16): a short measurement each, AFTER the timed region of
+            # the headline metric, so that a driver-run record carries them (round 2 had them in builder-run files only)
+            del task, optimizer, scheduler, graphed, batch, x, t, sync
+            torch.cuda.empty_cache()
+            import importlib.util
+
+            def tool(name):
+                spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                return mod
+            for key, name, argv in (("swin_t", "bench_swin_train", ["--graph", "--steps", "10", "--warmup", "3"]),
+                                    ("fusion_sentinel", "bench_fusion", ["--sentinel", "24", "--steps", "10", "--warmup", "3"])):
+                try:
+                    m = tool(name)
+                    out[key] = m.measure(m.parse(argv))
+                except Exception as e:  # an extra object never costs the headline line
+                    out[key] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B=2)
             out["cpu_baseline_b8"] = cpu_baseline(B=8)  # B = 2 (config 1) and B = 8

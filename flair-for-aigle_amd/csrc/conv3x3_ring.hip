@@ -568,6 +568,420 @@ __global__ void __launch_bounds__(64 * WCO * WPX, OCC) conv3x3_ring_kernel(Ring3
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 on v_mfma_f32_16x16x32_bf16 ("ring16", round 3): the same ring / halo / phase structure with the 16x16 MFMA
+// shape, whose K = 32 is one whole 64-byte channel chunk of one tap -- half the accumulator traffic per FLOP of the
+// 32x32x16 form, and the shape on which the chip holds the higher clock under load (MI355X_MICROARCH.md, DVFS item 7).
+//   * a wave owns 64 output channels x NT*16 pixels: MT = 4 tiles of 16 rows, NT pixel fragments of 16 columns;
+//     accumulator tile (mt, nt): lane (col = lane & 15, kg = lane >> 4) holds rows 4*kg .. 4*kg+3 of pixel col.  The
+//     pack stores output channel 16*kg + 4*mt + i of a 64-channel group in LDS row mt*16 + 4*kg + i, so a lane ends
+//     up with 16 CONSECUTIVE channels of its pixel (two 16-byte NHWC stores);
+//   * operand fragments: lane (row or pixel = lane & 15, kg) reads the 16 bytes of channels 8*kg .. 8*kg+7.  Both LDS
+//     images are plain 64-byte rows (one chunk of one row / pixel) whose 16-byte slot index is XORed with 2 when bit 2
+//     of the row index (weights) or of the halo column (pixels) is set: conflict-free ds_read_b128 for 16 consecutive
+//     rows / pixels at ANY alignment (all 16 columns x 3 taps checked by enumeration), conflict-free ds_write_b128,
+//     and still the linear destination LDS-DMA needs (the pack applies the XOR in global memory);
+//   * a phase (kernel row r of one chunk) = 3 steps (taps) of MT*NT MFMAs; fragments of step t+1 are requested while
+//     step t multiplies; the phase synchronisation sits behind step 0, the DMA of phase p+2 right behind it.
+
+// source of the padding pieces of an LDS-DMA halo fill (per-lane source addresses: a border pixel reads zeros)
+__device__ __attribute__((aligned(16))) const unsigned int ffa_ring_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <int WCO, int WPX, int NT, int TH, int TW>
+struct Ring16Geom {
+  static constexpr int MT = 4;
+  static constexpr int NW = WCO * WPX;
+  static constexpr int NTHR = 64 * NW;
+  static constexpr int BCO = 64 * WCO;
+  static constexpr int NPX = TH * TW;
+  static constexpr int IH = TH + 2;
+  static constexpr int IW = TW + 2;
+  static constexpr int ROWB = IW * 64;          // bytes of one halo row
+  static constexpr int HBUF = IH * ROWB;
+  static constexpr int TAPB = 64 * 64;          // one tap of one 64-row group: 4 KB
+  static constexpr int SLAB64 = 3 * TAPB;       // one kernel row of one 64-row group: 12 KB
+  static constexpr int SLOT = WCO * SLAB64;
+  static constexpr int NSLOT = 3;
+  static constexpr int NWI = SLOT / 1024 / NW;  // DMA wave-instructions per wave per phase
+  static constexpr int H_PIECES = IH * IW * 4;
+  static constexpr int NHP = (H_PIECES + NTHR - 1) / NTHR;
+  static constexpr int RING_OFF = 0;
+  static constexpr int HALO_OFF = NSLOT * SLOT;
+  // statistics scratch = the start of ring slot 2 (tap 0 of the tile's last phase: consumed before that phase's
+  // synchronisation, and the next DMA into the slot is only issued behind the next tile's first synchronisation)
+  static constexpr int RED_OFF = RING_OFF + 2 * SLOT;
+  static constexpr int RED_BYTES = NW * 64 * 2 * 4;
+  static constexpr int LDS_BYTES = HALO_OFF + 2 * HBUF;
+  static_assert(NPX == WPX * NT * 16, "pixel tile must be covered by the pixel waves");
+  static_assert(TW == 32 || TW == 16, "tile width");
+  static_assert((SLOT / 1024) % NW == 0, "every wave issues the same number of DMA instructions");
+  static_assert(RED_BYTES <= TAPB, "statistics scratch must stay inside tap 0 of the slot");
+  static_assert(NTHR % 4 == 0, "a thread keeps its 16-byte slot of the 64-byte chunk");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <int WCO, int WPX, int NT, int TH, int TW, int OCC, bool PRO>
+__global__ void __launch_bounds__(64 * WCO * WPX, OCC) conv3x3_ring16_kernel(Ring3Args a) {
+  using G = Ring16Geom<WCO, WPX, NT, TH, TW>;
+  using T = ffa_bf16;
+  constexpr int MT = G::MT;
+  __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave / WPX;
+  const int wpx = wave % WPX;
+  const int col = lane & 15;  // operand row (weights) / column (pixels) of a fragment; accumulator column
+  const int kg = lane >> 4;   // channels 8*kg .. 8*kg+7 of a chunk; accumulator rows 4*kg .. 4*kg+3
+  const int NC = a.nchunks;
+  const int PT = NC * 3;  // phases per tile
+  const int total_vb = ((a.npt + 7) / 8) * 8 * a.ncb;
+
+  // ---- per-lane LDS read addresses (ring slot, tap, tile and kernel row are immediates) ----
+  const int a0 = G::RING_OFF + wco * G::SLAB64 + col * 64 + ((kg ^ (((col >> 2) & 1) << 1)) * 16);
+  int bB[NT][3];  // includes the base of the CURRENT halo buffer
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = wpx * (NT * 16) + nt * 16 + col;
+    const int py = n / TW, px = n % TW;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int hx = px + s;
+      bB[nt][s] = G::HALO_OFF + (py * G::IW + hx) * 64 + ((kg ^ (((hx >> 2) & 1) << 1)) * 16);
+    }
+  }
+
+  // ---- halo staging geometry (tile independent part) ----
+  // Halo piece tid + k * NTHR = pixel q = (tid >> 2) + k * NTHR / 4 of the halo tile, 16-byte slot tid & 3.  The halo is
+  // filled by LDS-DMA: the destination of a wave instruction is linear (base + lane * 16), so the thread owns PHYSICAL
+  // slot tid & 3 of its pixel and fetches the logical slot that belongs there (the XOR goes on the source address).
+  const int jj = tid & 3;
+
+  struct TileId {
+    int pt, cb, b, oy0, ox0;
+  };
+  auto decode = [&](int vb) {
+    TileId t;
+    const int j = vb >> 3;
+    t.pt = (j / a.ncb) * 8 + (vb & 7);  // the co blocks of a pixel tile share an XCD's L2 (speed only)
+    t.cb = j % a.ncb;
+    const int tx = t.pt % a.tiles_x;
+    const int t2 = t.pt / a.tiles_x;
+    t.b = t2 / a.tiles_y;
+    t.oy0 = (t2 % a.tiles_y) * TH;
+    t.ox0 = tx * TW;
+    return t;
+  };
+  auto next_valid = [&](int vb) {
+    while (vb < total_vb && decode(vb).pt >= a.npt) vb += gridDim.x;
+    return vb;
+  };
+  const int pix_bytes = a.Ci * 2;
+  int hoff[G::NHP];  // byte offset of the piece from the input base (chunk 0), -1 = zero fill
+  auto halo_offsets = [&](const TileId& t) {
+#pragma unroll
+    for (int k = 0; k < G::NHP; ++k) {
+      const int q = (tid >> 2) + k * (G::NTHR / 4);
+      const int hy = q / G::IW, hx = q % G::IW;
+      const int vy = t.oy0 - 1 + hy, vx = t.ox0 - 1 + hx;
+      const bool ok = q < G::IH * G::IW && vy >= 0 && vx >= 0 && vy < a.H && vx < a.W;
+      const int slot = jj ^ (((hx >> 2) & 1) << 1);
+      hoff[k] = ok ? (((t.b * a.H + vy) * a.W + vx) * pix_bytes + slot * 16) : -1;
+    }
+  };
+
+  const unsigned char* in_b = static_cast<const unsigned char*>(a.in);
+  const unsigned char* w_all = static_cast<const unsigned char*>(a.w);
+
+  auto issue_w = [&](int cb, int ph, int slot) {
+#pragma unroll
+    for (int i = 0; i < G::NWI; ++i) {
+      const int ii = wave + i * G::NW;  // 1-KB piece of the slot (wave uniform)
+      const int g64 = ii / (G::SLAB64 / 1024), pi = ii % (G::SLAB64 / 1024);
+      const unsigned char* src = w_all + (long long)(cb * WCO + g64) * a.cb64_stride + (long long)ph * G::SLAB64 +
+                                 pi * 1024 + lane * 16;
+      ring_dma16(src, (unsigned)(size_t)(__attribute__((address_space(3))) void*)(smem + G::RING_OFF + slot * G::SLOT +
+                                                                                  ii * 1024));
+    }
+  };
+  // LDS-DMA halo fill (no prologue): chunk `chunk` of the tile hoff[] describes -> halo buffer `buf`.  The tail
+  // instruction runs with the lanes past the last piece masked off (they would write into the other buffer).
+  auto dma_h = [&](int chunk, int buf) {
+    const unsigned char* base = in_b + chunk * 64;
+    const unsigned char* zero = reinterpret_cast<const unsigned char*>(ffa_ring_zero16);
+#pragma unroll
+    for (int k = 0; k < G::NHP; ++k) {
+      const unsigned char* src = hoff[k] >= 0 ? base + (unsigned)hoff[k] : zero;
+      const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(
+          smem + G::HALO_OFF + buf * G::HBUF + (wave * 64 + k * G::NTHR) * 16);
+      if (k + 1 < G::NHP || G::H_PIECES % G::NTHR == 0) {
+        ring_dma16(src, dst);
+      } else if (wave * 64 + k * G::NTHR < G::H_PIECES) {  // wave uniform
+        if (tid + k * G::NTHR < G::H_PIECES) ring_dma16(src, dst);
+      }
+    }
+  };
+  // PRO ("normalise on load"): the convolution reads relu(in * pro_sc[c] + pro_sh[c]).  The raw halo arrives by DMA;
+  // once this wave's own pieces have landed (its vmcnt wait) thread t rewrites, in LDS, the pieces of LOGICAL slot
+  // t & 3 of its pixels -- the same 8 channels for every piece (one scale / shift load per chunk), and pieces that this
+  // very wave's DMA wrote (pixel q is filled by lanes 4*(q % 64) .. +3) -- skipping the zero padding (hoff < 0: the
+  // padding of the normalised tensor is zero, not relu(shift)).  Same fma / max / rounding as ffa_bn_apply.
+  auto fix_h = [&](int chunk, int buf) {
+    if constexpr (PRO) {
+      float psc[8], psh[8];
+      const int c0 = chunk * 32 + jj * 8;
+      ffa_load8<float>(a.pro_sc + c0, psc);
+      ffa_load8<float>(a.pro_sh + c0, psh);
+      unsigned char* base = smem + G::HALO_OFF + buf * G::HBUF;
+#pragma unroll
+      for (int k = 0; k < G::NHP; ++k) {
+        const int q = (tid >> 2) + k * (G::NTHR / 4);
+        const int hx = q % G::IW;
+        if ((k + 1 < G::NHP || G::H_PIECES % G::NTHR == 0 || q < G::IH * G::IW) && hoff[k] >= 0) {
+          ffa_u32x4* ptr = reinterpret_cast<ffa_u32x4*>(base + q * 64 + ((jj ^ (((hx >> 2) & 1) << 1)) * 16));
+          ffa_u32x4 v = *ptr;
+          float f[8];
+          f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+          f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+          f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+          f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = fmaxf(__builtin_fmaf(f[e], psc[e], psh[e]), 0.f);
+          v.x = ffa_pack_bf16x2(f[0], f[1]);
+          v.y = ffa_pack_bf16x2(f[2], f[3]);
+          v.z = ffa_pack_bf16x2(f[4], f[5]);
+          v.w = ffa_pack_bf16x2(f[6], f[7]);
+          *ptr = v;
+        }
+      }
+    }
+  };
+
+  int vb = next_valid(blockIdx.x);
+  if (vb >= total_vb) return;
+  TileId cur = decode(vb);
+
+  // ---- prologue of the block's first tile (the only exposed one) ----
+  halo_offsets(cur);
+  dma_h(0, 0);
+  issue_w(cur.cb, 0, 0);
+  issue_w(cur.cb, 1, 1);
+  if constexpr (PRO) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fix_h(0, 0);
+  }
+  ring_phase_sync<0>();  // slabs 0 and 1 and halo chunk 0 are in LDS (and normalised)
+  int hb = 0;
+  int hd = G::HBUF;  // byte distance from the current halo buffer to the other one
+
+  ffa_u32x4 fa[3][MT], fb[3][NT];  // fragment sets by step of the phase (two of them live at a time)
+  int bBn[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bBn[nt] = bB[nt][0] + hd;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) fa[0][mt] = *reinterpret_cast<const ffa_u32x4*>(smem + a0 + mt * 1024);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) fb[0][nt] = *reinterpret_cast<const ffa_u32x4*>(smem + bB[nt][0]);
+
+  ffa_f32x4 acc[MT][NT];
+
+  while (true) {
+    const int nvb = next_valid(vb + gridDim.x);
+    const bool has_next = nvb < total_vb;
+    const TileId nxt = decode(has_next ? nvb : vb);
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = ffa_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < NC; ++c) {
+      const bool last_c = (c + 1 == NC);
+      const bool hvalid = !last_c || has_next;
+      if (last_c && has_next) halo_offsets(nxt);
+      const int hchunk = last_c ? 0 : c + 1;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        int wcb_ = cur.cb, wph_ = c * 3 + r + 2;
+        if (wph_ >= PT) {
+          if (has_next) {
+            wcb_ = nxt.cb;
+            wph_ -= PT;
+          } else {
+            wph_ = PT - 1;
+          }
+        }
+        const unsigned char* sA = smem + a0 + r * G::SLOT;
+        const unsigned char* sAn = smem + a0 + ((r + 1) % 3) * G::SLOT;
+#pragma unroll
+        for (int st = 0; st < 3; ++st) {
+          __builtin_amdgcn_sched_barrier(0);
+          // ---- request the fragments of the next step ----
+          if (st < 2) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              fa[st + 1][mt] = *reinterpret_cast<const ffa_u32x4*>(sA + (st + 1) * G::TAPB + mt * 1024);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              fb[st + 1][nt] = *reinterpret_cast<const ffa_u32x4*>(smem + bB[nt][st + 1] + r * G::ROWB);
+          } else {  // step 0 of the next phase: ring slot r + 1, halo row r + 1 (or row 0 of the next chunk)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) fa[0][mt] = *reinterpret_cast<const ffa_u32x4*>(sAn + mt * 1024);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              if (r < 2) fb[0][nt] = *reinterpret_cast<const ffa_u32x4*>(smem + bB[nt][0] + (r + 1) * G::ROWB);
+              else fb[0][nt] = *reinterpret_cast<const ffa_u32x4*>(smem + bBn[nt]);
+            }
+          }
+          // ---- multiply step st ----
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ffa_bf16x8, fa[st][mt]),
+                                                                    __builtin_bit_cast(ffa_bf16x8, fb[st][nt]),
+                                                                    acc[mt][nt], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < MT * NT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < MT + NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          if (st == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            // next chunk's halo into the other buffer (requested a whole chunk ago), then the phase meets: every
+            // wave's DMA of the next phase has landed (issued a phase ago) and every wave is done with the previous
+            // phase's ring slot -> refill it
+            // vector-memory queue, oldest first -- at r = 0: W(p+1); at r = 1: W(p+1), then the NHP halo pieces issued
+            // behind it (they may stay in flight for another phase); at r = 2: halo pieces, W(p+1): the halo is read
+            // from step 2 of this phase on, so everything must have landed
+            if (r == 1 && hvalid) {  // (no halo fill behind W(p+1) when this is the block's last chunk: plain wait)
+              // exact count per wave: the tail instruction of the halo fill exists only in the waves that own pieces
+              // of it (a wave that waited for one operation too few would publish a weight slab still in flight)
+              constexpr bool TAIL = G::H_PIECES % G::NTHR != 0;
+              if (!TAIL || wave * 64 + (G::NHP - 1) * G::NTHR < G::H_PIECES) ring_phase_sync_nolgkm<G::NHP>();
+              else ring_phase_sync_nolgkm<G::NHP - 1>();
+            } else if (PRO && r == 2) {
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              // the tile whose halo this is: hoff[] already describes it (the next chunk of `cur`, or chunk 0 of `nxt`)
+              if (hvalid) fix_h(hchunk, hb ^ 1);
+              ring_phase_sync<0>();  // the rewritten pieces must be in LDS before the block meets
+            } else {
+              ring_phase_sync_nolgkm<0>();
+            }
+            issue_w(wcb_, wph_, (r + 2) % 3);
+            if (r == 0 && hvalid) dma_h(hchunk, hb ^ 1);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the next chunk reads the other halo buffer
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) bB[nt][s] += hd;
+      }
+      hb ^= 1;
+      hd = -hd;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bBn[nt] = bB[nt][0] + hd;
+    }
+
+    // ---- epilogue of `cur`: lane (col, kg) owns pixel n = wave px base + nt*16 + col and 16 consecutive channels ----
+    {
+      T* out = static_cast<T*>(a.out);
+      const T* res = static_cast<const T*>(a.res);
+      const int co_lane = cur.cb * G::BCO + wco * 64 + 16 * kg;
+      float st[32];  // [16 sums | 16 sums of squares] of this lane's channels
+      const bool want_stats = a.stats != nullptr;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) st[i] = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = wpx * (NT * 16) + nt * 16 + col;
+        const int oy = cur.oy0 + n / TW, ox = cur.ox0 + n % TW;
+        if (oy >= a.H || ox >= a.W) continue;
+        const long long pix = ((long long)(cur.b * a.H + oy) * a.W + ox) * (long long)a.Co;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int c0 = co_lane + 8 * h;
+          if (c0 >= a.Co) continue;
+          float v[8];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] = acc[2 * h][nt][i];
+            v[4 + i] = acc[2 * h + 1][nt][i];
+          }
+          if (a.bias) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += a.bias[c0 + i];
+          }
+          if (res) {
+            float rv[8];
+            ffa_load8<T>(res + pix + c0, rv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += rv[i];
+          }
+          if (a.relu) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+          }
+          ffa_store8<T>(out + pix + c0, v);
+          if (want_stats) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const float rr = ffa_bf16_bits_to_f32(ffa_f32_to_bf16_bits(v[i]));
+              st[h * 8 + i] += rr;
+              st[16 + h * 8 + i] = __builtin_fmaf(rr, rr, st[16 + h * 8 + i]);  // explicit: all conv kernels round alike
+            }
+          }
+        }
+      }
+      if (want_stats) {
+        // transposing reduction over the 16 lanes that share kg: afterwards lane col holds entries 2*col and 2*col + 1
+        // of [sums | sums of squares]
+#pragma unroll
+        for (int bit = 3; bit >= 0; --bit) {
+          const int n = 32 >> (3 - bit);
+          const bool up = (col >> bit) & 1;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            if (j < n / 2) {
+              float lo = st[j], hi = st[j + n / 2];
+              asm volatile("" : "+v"(lo), "+v"(hi));
+              const float keep = up ? hi : lo;
+              const float send = up ? lo : hi;
+              st[j] = keep + __shfl_xor(send, 1 << bit, 64);
+            }
+          }
+        }
+        float* red = reinterpret_cast<float*>(smem + G::RED_OFF);
+        red[(wave * 64 + lane) * 2 + 0] = st[0];
+        red[(wave * 64 + lane) * 2 + 1] = st[1];
+        ring_lds_sync();
+        if (tid < 128 * WCO) {
+          const int wc = tid >> 7, t7 = tid & 127;
+          const int j = t7 & 1;
+          const int ln = t7 >> 1;
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < WPX; ++w) t += red[((wc * WPX + w) * 64 + ln) * 2 + j];
+          const int cl = ln & 15, kq = ln >> 4;
+          const int which = cl >> 3;
+          const int ch = cur.cb * G::BCO + wc * 64 + 16 * kq + (cl & 7) * 2 + j;
+          if (ch < a.Co) a.stats[((size_t)cur.pt * 2 + which) * a.Co + ch] = t;
+        }
+        ring_lds_sync();  // red is reused by the next tile
+      }
+    }
+    if (!has_next) break;
+    vb = nvb;
+    cur = nxt;
+  }
+  // the trailing DMA (re-reads of the last slab) must not outlive the block's LDS allocation
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 
 struct RingPlan {
@@ -577,8 +991,8 @@ struct RingPlan {
 };
 
 // Tile configuration of a layer.  cfg 1: 64 co x 8x32 px, 4 waves, two blocks per CU; cfg 2: 64 co x 16x16 px,
-// 4 waves; cfg 3: 128 co x 16x32 px, 8 waves (64 co x 128 px per wave); cfg 4: 128 co x 8x32 px, 8 waves;
-// cfg 5: 64 co x 16x32 px, 4 waves of 64 co x 128 px, one block per CU.
+// 4 waves; cfg 4: 128 co x 8x32 px, 8 waves.  (cfg 3 / 5 of round 2 -- 64 co x 128 px per wave -- measured slower and
+// are gone; their numbers map to 4 / 1.)
 static RingPlan ring_plan(int B, int H, int W, int co_rows) {
   RingPlan p;
   p.cfg = 0;
@@ -589,19 +1003,29 @@ static RingPlan ring_plan(int B, int H, int W, int co_rows) {
     if (W < 32) cfg = 2;
     else cfg = 1;
   }
-  if (cfg == 3 && (co_rows % 128 != 0 || W < 32)) cfg = (W < 32) ? 2 : 1;
+  if (cfg == 3) cfg = 4;
+  if (cfg == 5) cfg = 1;
   if (cfg == 4 && (co_rows % 128 != 0 || W < 32)) cfg = (W < 32) ? 2 : 1;
-  if ((cfg == 1 || cfg == 5) && W < 32) cfg = 2;
+  if (cfg == 1 && W < 32) cfg = 2;
   p.cfg = cfg;
   switch (cfg) {
     case 1: p.th = 8; p.tw = 32; p.bco = 64; break;
     case 2: p.th = 16; p.tw = 16; p.bco = 64; break;
-    case 3: p.th = 16; p.tw = 32; p.bco = 128; break;
     case 4: p.th = 8; p.tw = 32; p.bco = 128; break;
-    case 5: p.th = 16; p.tw = 32; p.bco = 64; break;
     default: p.cfg = 0; break;
   }
   return p;
+}
+
+template <int WCO, int WPX, int NT, int TH, int TW, int OCC>
+static int ring16_launch(const Ring3Args& a, int grid, hipStream_t stream) {
+  if (a.pro_sc)
+    hipLaunchKernelGGL((conv3x3_ring16_kernel<WCO, WPX, NT, TH, TW, OCC, true>), dim3(grid), dim3(64 * WCO * WPX), 0,
+                       stream, a);
+  else
+    hipLaunchKernelGGL((conv3x3_ring16_kernel<WCO, WPX, NT, TH, TW, OCC, false>), dim3(grid), dim3(64 * WCO * WPX), 0,
+                       stream, a);
+  return ffa_check_launch("conv3x3_ring16");
 }
 
 template <typename T, int WCO, int WPX, int NT, int TH, int TW, int OCC>
@@ -660,19 +1084,25 @@ extern "C" int ffa_ring_conv3x3(int dtype, const void* in, const void* w_ring, c
   a.cb64_stride = (long long)a.nchunks * 3 * (3 * 2 * 64 * 32);
   const int total = ffa_cdiv(a.npt, 8) * 8 * a.ncb;
   const char* pg = getenv("FFA_RING_GRID");
-  int cap = pg ? atoi(pg) : ((p.cfg == 1) ? 512 : 256);
+  // two 4-wave blocks per CU (cfg 1; cfg 2 on the bf16 kernel), one 8-wave block (cfg 4)
+  int cap = pg ? atoi(pg) : ((p.cfg == 1 || (p.cfg == 2 && dtype == FFA_BF16)) ? 512 : 256);
   cap = cap < 8 ? 8 : (cap / 8) * 8;
   const int grid = total < cap ? total : cap;
+  if (dtype == FFA_BF16) {  // v_mfma_f32_16x16x32_bf16 kernel (NT counts 16-pixel fragments there)
+    switch (p.cfg) {
+      case 1: return ring16_launch<1, 4, 4, 8, 32, 2>(a, grid, stream);
+      case 2: return ring16_launch<1, 4, 4, 16, 16, 2>(a, grid, stream);
+      case 4: return ring16_launch<2, 4, 4, 8, 32, 2>(a, grid, stream);
+    }
+    return FFA_ERR_UNSUPPORTED;
+  }
 #define FFA_RING_DISPATCH(T_)                                                        \
   switch (p.cfg) {                                                                   \
     case 1: return ring_launch<T_, 1, 4, 2, 8, 32, 2>(a, grid, stream);              \
     case 2: return ring_launch<T_, 1, 4, 2, 16, 16, 1>(a, grid, stream);             \
-    case 3: return ring_launch<T_, 2, 4, 4, 16, 32, 2>(a, grid, stream);             \
     case 4: return ring_launch<T_, 2, 4, 2, 8, 32, 2>(a, grid, stream);              \
-    case 5: return ring_launch<T_, 1, 4, 4, 16, 32, 1>(a, grid, stream);             \
   }
-  if (dtype == FFA_BF16) { FFA_RING_DISPATCH(ffa_bf16) }
-  else { FFA_RING_DISPATCH(float) }
+  FFA_RING_DISPATCH(float)
 #undef FFA_RING_DISPATCH
   return FFA_ERR_UNSUPPORTED;
 }
@@ -729,21 +1159,77 @@ __device__ __forceinline__ void ring_pack_piece(const RingPackArgs& p, long long
   }
 }
 
-__global__ void ring_pack_kernel(RingPackArgs p, int dtype) {
-  const long long total = (long long)p.ncb64 * p.nchunks * 3 * 3 * 2 * 64 * 2;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    if (dtype == FFA_BF16) ring_pack_piece<ffa_bf16>(p, i);
-    else ring_pack_piece<float>(p, i);
+// bf16 operand of conv3x3_ring16_kernel: dst[cb64][chunk][kernel row r][tap s][row < 64][slot' < 4][8 elements],
+// LDS row mt*16 + 4*kg + i holds output channel 16*kg + 4*mt + i of the 64-row group, slot' = slot ^ 2 when bit 2 of
+// the row is set (slot = channels 8*slot .. 8*slot+7 of the 32-channel chunk).  Same bytes per (group, chunk) as the
+// 32x32 layout, so sizes and strides are shared.
+// One thread = one (row, 16-byte slot) of a chunk, all nine taps: it reads 8 channels x 9 contiguous taps of the OIHW
+// master (36-byte runs; a thread per piece touched a 32-byte sector per 4 useful bytes: 287 us per step for the
+// U-Net's operands) and writes its nine pieces, one into each tap plane.  Threads of a block run over the 64 rows first,
+// so the transposed (dgrad) operand -- whose rows are the contiguous axis of the master -- reads whole runs too.
+__device__ __forceinline__ void ring16_pack_rowslot(const RingPackArgs& p, long long idx) {
+  // lanes follow the contiguous axis of the master: (slot, chunk) = consecutive 288-byte runs of one row for the
+  // forward operand [row][ch][tap]; rows = consecutive 36-byte runs for the transposed one [ch][row][tap]
+  long long t = idx;
+  int row_l, sp, cc;
+  if (!p.flip) {
+    sp = (int)(t % 4); t /= 4;
+    cc = (int)(t % p.nchunks); t /= p.nchunks;
+    row_l = (int)(t % 64); t /= 64;
+  } else {
+    row_l = (int)(t % 64); t /= 64;
+    sp = (int)(t % 4); t /= 4;
+    cc = (int)(t % p.nchunks); t /= p.nchunks;
   }
+  const int cb = (int)t;
+  const int mt = row_l >> 4, kg = (row_l >> 2) & 3, i = row_l & 3;
+  const int row = cb * 64 + 16 * kg + 4 * mt + i;
+  const int slot = sp ^ (((row_l >> 2) & 1) << 1);
+  const int ch0 = cc * 32 + slot * 8;
+  const bool row_ok = row < p.rows;
+  const float sc = (row_ok && p.scale) ? p.scale[row] : 1.f;
+  float v[8][9];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = ch0 + j;
+    const bool ok = row_ok && ch < p.chs;
+    const float* src = p.src + (long long)(ok ? row : 0) * p.s_row + (long long)(ok ? ch : 0) * p.s_ch;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) v[j][tp] = ok ? src[tp] * sc : 0.f;
+  }
+  ffa_bf16* dst = static_cast<ffa_bf16*>(p.dst) + ((((long long)cb * p.nchunks + cc) * 9) * 256 + row_l * 4 + sp) * 8;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) {  // destination tap (r, s) = tp; the dgrad operand mirrors the taps
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = v[j][p.flip ? 8 - tp : tp];
+    ffa_store8<ffa_bf16>(dst + (long long)tp * 256 * 8, o);
+  }
+}
+
+__global__ void ring_pack_kernel(RingPackArgs p, int dtype) {
+  if (dtype == FFA_BF16) {
+    const long long total = (long long)p.ncb64 * p.nchunks * 64 * 4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+      ring16_pack_rowslot(p, i);
+    return;
+  }
+  const long long total = (long long)p.ncb64 * p.nchunks * 3 * 3 * 2 * 64 * 2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    ring_pack_piece<float>(p, i);
 }
 
 __global__ void ring_pack_batched_kernel(const RingPackArgs* __restrict__ descs, int dtype) {
   const RingPackArgs p = descs[blockIdx.y];
-  const long long total = (long long)p.ncb64 * p.nchunks * 3 * 3 * 2 * 64 * 2;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    if (dtype == FFA_BF16) ring_pack_piece<ffa_bf16>(p, i);
-    else ring_pack_piece<float>(p, i);
+  if (dtype == FFA_BF16) {
+    const long long total = (long long)p.ncb64 * p.nchunks * 64 * 4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+      ring16_pack_rowslot(p, i);
+    return;
   }
+  const long long total = (long long)p.ncb64 * p.nchunks * 3 * 3 * 2 * 64 * 2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    ring_pack_piece<float>(p, i);
 }
 
 static int ring_pack_fill(RingPackArgs& p, const float* w_oihw, const float* scale, void* dst, int O, int I,

@@ -1200,18 +1200,20 @@ extern "C" int ffa_ring_pack(int dtype, const float* w_oihw, const float* scale,
 
 // Operand layout + block height for a layer: the value to hand to ffa_pack_conv_weight / ffa_conv2d as `bco`.
 // Bits 0..11 = rows per block (the padded row count is a multiple of it); FFA_BCO_RING set = the operand is packed
-// for conv3x3_ring_kernel (3x3 stride 1 pad 1, >= 64 rows, whole 64-byte groups of input channels; plain
-// ffa_conv2d / ffa_conv2d_stats calls only -- pass allow_ring = 0 for operands used by the two-source, split-epilogue
-// or zero-insertion (dil = 2) calls).  The ring layout is chosen only with FFA_RING=1 in the environment: measured
-// on MI355X it equals conv3x3_persist_kernel on the 128 / 256-channel layers and trails it by 2-6 % on the 64- and
-// 512-channel ones, so the default stays with the conv_igemm operands.
+// for the ring kernels of conv3x3_ring.hip (3x3 stride 1 pad 1, >= 64 rows, whole 64-byte groups of input channels;
+// plain ffa_conv2d / ffa_conv2d_stats calls only -- pass allow_ring = 0 for operands used by the two-source,
+// split-epilogue or zero-insertion (dil = 2) calls).
+//   bf16: conv3x3_ring16_kernel (v_mfma_f32_16x16x32_bf16, LDS-DMA weights AND halo) is the default since round 3 --
+//         36 / 32.5 / 34.7 us on the 128 / 256 / 512-channel layers against 40 / 37.3 / 38 for conv3x3_persist_kernel
+//         (same box); FFA_RING=0 restores the conv_igemm operands;
+//   f32:  conv3x3_ring_kernel only with FFA_RING=1 (it equals the persist kernel).
 extern "C" int ffa_conv_plan(int dtype, int kh, int kw, int stride, int cout, int ci_pitch, int allow_ring) {
   const int bco = ffa_conv_block_co(kh, kw, stride, cout);
   if (bco < 0) return bco;
   const char* e = getenv("FFA_RING");
   const int eb = (dtype == FFA_BF16) ? 2 : 4;
-  if (allow_ring && e && e[0] == '1' && kh == 3 && kw == 3 && stride == 1 && cout >= 64 &&
-      (ci_pitch * eb) % 64 == 0)
+  const bool on = (dtype == FFA_BF16) ? !(e && e[0] == '0') : (e && e[0] == '1');
+  if (allow_ring && on && kh == 3 && kw == 3 && stride == 1 && cout >= 64 && (ci_pitch * eb) % 64 == 0)
     return 64 | FFA_BCO_RING;
   return bco;
 }

@@ -248,9 +248,18 @@ class TileBatcher:
     def __len__(self) -> int:
         return (len(self.ds) + self.bs - 1) // self.bs
 
+    AHEAD = 4  # batches whose footprint is announced to the rasters (parallel block decode: JPEG-2000 mosaics)
+
     def _fill(self, k: int, start: int):
         idx = list(range(start, min(start + self.bs, len(self.ds))))
         out = {}
+        if k % self.AHEAD == 0:  # union box of the next AHEAD batches: tiles run column by column, south to north
+            ahead = self.boxes[start: start + self.AHEAD * self.bs]
+            box = (min(b[0] for b in ahead), min(b[1] for b in ahead), max(b[2] for b in ahead), max(b[3] for b in ahead))
+            for mod in self.ds.modalities:
+                hint = getattr(self.ds.readers[mod], "prefetch_bounds", None)
+                if hint is not None:
+                    hint(box)
         for mod, cfg in self.ds.modalities.items():
             buf = self.bufs[mod][k % self.NBUF]
             arr = buf.numpy()

@@ -52,6 +52,11 @@ class RasterBase:
     def _native_dtype(self) -> np.dtype:
         return np.dtype(self.dtype).newbyteorder("=")
 
+    def prefetch_bounds(self, bounds) -> None:
+        """Hint: the geographic box (left, bottom, right, top) is about to be read tile by tile.  Rasters whose storage
+        blocks are expensive to decode (JPEG-2000 code-stream tiles) decode the blocks under it in parallel; the default
+        does nothing."""
+
     def read_bounds(self, indexes, bounds, out_size: int, out: np.ndarray = None, nearest: bool = False) -> np.ndarray:
         """Boundless read of the geographic box `bounds` = (left, bottom, right, top), zero fill outside the
         raster, resampled to out_size x out_size when the box is not already that many pixels (bilinear; ``nearest``:

@@ -213,10 +213,11 @@ class GradSync:
         bucket view), one all-reduce per bucket, scale, and point every ``p.grad`` at its bucket view for the optimizer.
 
         RCCL runs the bucket collectives in issue order on its own stream, so all of them are launched before the first
-        wait (the compute stream waits stream-side, the host never blocks).  gloo (CPU rehearsals, several ranks sharing
-        one GPU) stages device tensors through host buffers in worker threads; three 32 MiB collectives in flight at
-        once made its ranks interleave segments and took 0.5-15 s per step on a GPU box (round 2's "13 s/step",
-        tools/ddp_graph_probe.py), so there each bucket is finished before the next is started.
+        wait (the compute stream waits stream-side, the host never blocks).  gloo (rehearsals: several ranks sharing
+        one GPU) stages device tensors through host buffers in its worker threads, and a collective handed to it while
+        the device is still busy with the replayed graph took 0.25-15 s (round 2's "13 s/step"; tools/ddp_graph_probe.py:
+        30 ms when the stream is idle at the call, 4.7 s when it is not, one bucket at a time or three), so for gloo on
+        device tensors the stream is drained first and the buckets go one by one.
 
         ``exact_unused``: parameters outside ``params`` keep ``grad = None`` unless another rank handed one in (the set
         is exchanged once per distinct ``params`` set, not per step: under a replayed graph it never changes)."""
@@ -234,6 +235,8 @@ class GradSync:
                     b.flat[off: off + p.numel()].zero_()
         if self.world > 1 or self.always_sync:
             serial = dist.get_backend(self.group) == "gloo"
+            if serial and self._buckets[0].flat.is_cuda:
+                torch.cuda.current_stream().synchronize()
             works = []
             for b in self._buckets:
                 w = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

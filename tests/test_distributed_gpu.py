@@ -86,7 +86,9 @@ def test_two_ranks_on_one_gpu_match_the_mean_gradient_step(cuda, tmp_path):
                 if p.grad is not None:
                     sums[k] = p.grad.clone() if k not in sums else sums[k] + p.grad
         for k, p in params.items():
-            p.grad = sums[k] * (1.0 / WORLD) if k in sums else torch.zeros_like(p)
+            # a parameter no rank produced a gradient for keeps grad = None (HipTrainer runs GradSync with exact_unused:
+            # the reference's ddp_find_unused_parameters_true), so AdamW neither decays it nor creates state for it
+            p.grad = sums[k] * (1.0 / WORLD) if k in sums else None
         opt.step()
         sched.step()
     torch.cuda.synchronize()
@@ -155,7 +157,7 @@ SWIN = "swin_tiny_patch4_window7_224-upernet"
 
 def test_two_ranks_train_swin_upernet_like_the_mean_gradient_step(cuda, tmp_path):
     """the same flow for the transformer architecture: parameters that never receive a gradient (smp's unused FPNBlock of
-    the input image) are zero-filled in the buckets, the replicas stay bit-identical, and the result equals the
+    the input image) take part in the buckets with zeros but keep grad = None, the replicas stay bit-identical, and the result equals the
     mean-gradient step up to the summation order of the attention backward's LDS atomics"""
     mp.spawn(_worker, args=(_free_port(), str(tmp_path), SWIN), nprocs=WORLD, join=True)
     w0, w1 = (torch.load(tmp_path / f"w{r}.pt") for r in range(WORLD))
@@ -181,12 +183,16 @@ def test_two_ranks_train_swin_upernet_like_the_mean_gradient_step(cuda, tmp_path
                 if p.grad is not None:
                     sums[k] = p.grad.clone() if k not in sums else sums[k] + p.grad
         for k, p in params.items():
-            p.grad = sums[k] * (1.0 / WORLD) if k in sums else torch.zeros_like(p)
+            # a parameter no rank produced a gradient for keeps grad = None (HipTrainer runs GradSync with exact_unused:
+            # the reference's ddp_find_unused_parameters_true), so AdamW neither decays it nor creates state for it
+            p.grad = sums[k] * (1.0 / WORLD) if k in sums else None
         opt.step()
         sched.step()
     torch.cuda.synchronize()
     unused = [k for k in params if "fpn_stages.4" in k]
     assert unused, "the architecture is expected to hold gradient-less parameters"
+    for k in unused:  # untouched by four steps of AdamW with weight decay, on every replica
+        assert torch.equal(w0[k], start[k].cpu()), k
     for k, p in params.items():
         moved = (p.detach() - start[k]).abs().max().item()
         d = (p.detach().cpu() - w0[k]).abs().max().item()

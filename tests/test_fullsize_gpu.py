@@ -258,3 +258,54 @@ def test_bf16_at_full_tile_size_against_the_oracle(cuda):
     assert lrel <= 1e-3
     assert head_err <= 2e-2
     assert gcos >= 0.5 and 0.9 <= (n1 / n2) ** 0.5 <= 1.1  # measured: cosine 0.68, norm ratio 0.987
+
+
+def test_bf16_parameter_gradients_are_as_close_to_fp32_as_the_oracles_own_bf16_storage_run(cuda):
+    """Round-2 review, weak #2: the benchmarked mode had only a direction check (cosine >= 0.5) on whole-model gradients.
+    The oracle has a bf16-STORAGE mode now (oracle/unet_resnet34.py: every tensor the product materialises in bf16 is
+    rounded at the same point, forward and backward, f32 arithmetic in between).  Measured first: the product does NOT
+    track that evaluation element by element either (per-parameter relative error 0.72, cosine 0.62 at 2 x 512 x 512) --
+    a one-ulp difference of one stored bf16 activation (the f32 sums of two implementations differ in the last bits, 5e-4
+    of the elements round the other way) moves ~600 outputs of the next convolution by ~1e-4 relative, of which ~5 %
+    cross a bf16 rounding boundary in turn: the difference avalanches, and after a few layers two bf16-storage
+    evaluations are as far from each other as each is from the float32 one.  What CAN be bounded parameter by parameter
+    is the distance to the float32 gradient, with the reference arithmetic's own bf16-storage evaluation as the
+    yardstick (the form of the fp32 test above, one precision level down): a mis-scaled or partly wrong layer shows as a
+    product error well above the yardstick for its parameters, and as a norm ratio away from 1."""
+    task, oracle32, _ = make_pair(precision="bf16")
+    from oracle.unet_resnet34 import UnetResNet34
+    oracle16 = UnetResNet34(5, 19, storage_dtype=torch.bfloat16)
+    oracle16.load_state_dict(oracle32.state_dict())
+    x, t = _batch(2, seed=23)
+    batch = {MOD: x.to(cuda), TASK: t.to(cuda)}
+    grads = {}
+    for tag, orc in (("f32", oracle32), ("b16", oracle16)):
+        orc.train()
+        loss_o = F.cross_entropy(orc(x), t, weight=WEIGHTS)
+        loss_o.backward()
+        grads[tag] = {k: p.grad.double().flatten() for k, p in orc.named_parameters()}
+        grads[tag + "_loss"] = loss_o.item()
+    task.train()
+    loss, _, _ = task.step(batch, training=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    lrel = abs(loss.item() - grads["b16_loss"]) / abs(grads["b16_loss"])
+    ratio, nrm, yard = {}, {}, {}
+    for name, p in task.model.named_parameters():
+        if name.startswith("fusion_handler."):
+            continue
+        ok = ("encoder." if name.startswith("encoders.") else "") + name.split(".seg_model.", 1)[1]
+        a, r32, r16 = p.grad.double().cpu().flatten(), grads["f32"][ok], grads["b16"][ok]
+        e_hip = float((a - r32).norm() / r32.norm())
+        e_orc = float((r16 - r32).norm() / r32.norm())
+        yard[ok], ratio[ok], nrm[ok] = e_orc, e_hip / max(e_orc, 1e-3), float(a.norm() / r16.norm())
+    rv = sorted(ratio.values())
+    worst = max(ratio, key=ratio.get)
+    print(f"bf16 product vs fp32 oracle, yardstick = the oracle's own bf16-storage run, 2 x 512 x 512: loss rel {lrel:.2e} "
+          f"(vs the bf16-storage oracle); yardstick error median {sorted(yard.values())[len(yard) // 2]:.3f}; "
+          f"product error / yardstick: median {rv[len(rv) // 2]:.3f}, 90th percentile {rv[int(len(rv) * 0.9)]:.3f}, "
+          f"worst {ratio[worst]:.3f} at {worst}; gradient norm product / bf16-storage oracle: "
+          f"{min(nrm.values()):.3f} .. {max(nrm.values()):.3f}")
+    assert lrel <= 2e-4
+    assert ratio[worst] <= 1.5 and rv[len(rv) // 2] <= 1.15
+    assert 0.85 <= min(nrm.values()) and max(nrm.values()) <= 1.18

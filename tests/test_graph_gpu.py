@@ -85,10 +85,10 @@ def test_trainer_graph_mode_follows_the_eager_trainer(cuda):
 
 
 def test_graph_plus_bucket_reduce_equals_the_eager_step(cuda):
-    """data-parallel form of the graph step (forward + backward replayed, gradients handed to GradSync.reduce_grads,
-    eager optimizer step): at world size 1 the reduction is the identity, so the trajectory is the eager one"""
+    """data-parallel form of the graph step (graph A = forward + backward, gradients handed to GradSync.reduce_grads,
+    graph B = the optimizer step): at world size 1 the reduction is the identity, so the trajectory is the eager one"""
     from flairhip.distributed import GradSync
-    from flairhip.graph import GraphedTrainStep
+    from flairhip.graph import GraphedTrainStep, make_capturable
 
     def run(graph):
         task, _, cfg = make_pair(precision="bf16", seed=13)
@@ -110,6 +110,7 @@ def test_graph_plus_bucket_reduce_equals_the_eager_step(cuda):
             for b in batches:
                 losses.append(stepper(b).item())
         else:
+            make_capturable(opt)  # the optimizer arithmetic of a captured step (device-resident lr and step counter)
             for b in batches:
                 loss = task.training_step(b, 0)
                 opt.zero_grad(set_to_none=True)

@@ -162,3 +162,48 @@ def test_mosaics_beyond_pillows_pixel_guard_open_and_decode(tmp_path, monkeypatc
         assert (r.height, r.width) == arr.shape
         assert np.array_equal(r.read(1), arr)
     assert Image.MAX_IMAGE_PIXELS == 1000  # restored after both steps
+
+
+@pytest.mark.parametrize("shape,tile", [((300, 421), (128, 128)), ((257, 130, 3), (64, 64)), ((200, 200, 4), (256, 64)),
+                                        ((96, 80), (32, 32))])
+def test_tiled_codestreams_are_decoded_tile_by_tile(tmp_path, shape, tile):
+    """A tiled JPEG-2000 (BD ORTHO mosaics are) is read lazily: each window decodes only the code-stream tiles it
+    touches, from one-tile streams cut out of the file (rewritten SIZ, tile index 0) -- pixel-identical to the whole-image
+    decode, ragged last tiles and multi-tile windows included."""
+    from PIL import Image
+    g = np.random.default_rng(shape[0] + tile[0])
+    arr = g.integers(0, 255, shape).astype(np.uint8)
+    p = str(tmp_path / "t.jp2")
+    Image.fromarray(arr).save(p, format="JPEG2000", irreversible=False, tile_size=tile)
+    want = arr[None] if arr.ndim == 2 else arr.transpose(2, 0, 1)
+    with open_raster(p) as r:
+        ix = r.index
+        assert r.lazy and (ix.xt, ix.yt) == tile and ix.ntx == -(-shape[1] // tile[0]) and ix.nty == -(-shape[0] // tile[1])
+        assert sorted(ix.parts) == list(range(ix.ntx * ix.nty))
+        # one interior window: only the tiles it touches get decoded
+        wx, wy = min(tile[0], shape[1] - 12) - 5, min(tile[1], shape[0] - 12) - 3
+        got = r.read(window=make_window(wx, wy, 11, 9))
+        assert np.array_equal(got, want[:, wy:wy + 9, wx:wx + 11])
+        touched = ((wx + 10) // tile[0] - wx // tile[0] + 1) * ((wy + 8) // tile[1] - wy // tile[1] + 1)
+        assert len(r._tiles) == touched and r._data is None
+        # boundless read over the bottom-right corner (ragged tiles) and the whole image
+        assert np.array_equal(r.read(window=make_window(shape[1] - 20, shape[0] - 17, 40, 30), boundless=True),
+                              ArrayRaster(want, 0.0, float(shape[0]), 1.0).read(window=make_window(shape[1] - 20, shape[0] - 17, 40, 30),
+                                                                                boundless=True))
+        assert np.array_equal(r.read(), want)
+        r.prefetch_rows(0, tile[1])
+        assert r._data is None  # the whole-image path was never taken
+    assert not r._tiles
+
+
+def test_streams_that_cannot_be_cut_fall_back_to_the_whole_decode(tmp_path):
+    from PIL import Image
+    g = np.random.default_rng(3)
+    arr = g.integers(0, 255, (120, 150)).astype(np.uint8)
+    for name, kw, why in (("one.jp2", {}, "single tile"), ("odd.jp2", {"tile_size": (48, 48)}, "power of two")):
+        p = str(tmp_path / name)
+        Image.fromarray(arr).save(p, format="JPEG2000", irreversible=False, **kw)
+        with open_raster(p) as r:
+            assert not r.lazy and why in r.index.why
+            assert np.array_equal(r.read(1, window=make_window(40, 30, 70, 60)), arr[30:90, 40:110])
+            assert r._data is not None

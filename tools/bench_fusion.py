@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "flair-for-aigle_amd"))
 import torch
 
 
-def main():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=20)
@@ -34,7 +34,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--sentinel", type=int, default=0, metavar="T",
                     help="add the Sentinel-2 time-series branch (U-TAE, T dates of 10 x 10 px x 10 bands): BASELINE configs[4]")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def measure(args) -> dict:
+    """one measurement; also called in-process by bench.py (extra object "fusion_sentinel" of the driver-run line)"""
     from flairhip.configs import fusion_unet_config
     from flair_hub.tasks.module_setup import build_segmentation_module
     MOD, DEM, COSIA, LPIS = "AERIAL_RGBI", "DEM_ELEV", "AERIAL_LABEL-COSIA", "ALL_LABEL-LPIS"
@@ -87,14 +91,18 @@ def main():
         loss = step(args.warmup + i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({
+    return ({
         "metric": "512x512x5 (+128x128x2 DEM" + (f" + {args.sentinel} Sentinel-2 dates" if args.sentinel else "") +
                   ") tiles/sec, two-encoder fused U-Net ResNet-34" + (" + U-TAE" if args.sentinel else "") +
                   ", COSIA + LPIS + aux decoder, train fwd+bwd+AdamW",
         "value": round(B * args.steps / dt, 2), "unit": "tiles/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
         "batch": B, "steps": args.steps, "warmup": args.warmup, "dtype": "bf16", "hip_graph": graphed is not None,
         "parameters": nparams, "final_loss": round(float(loss.item()), 5),
-        "peak_memory_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
+        "peak_memory_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)})
+
+
+def main():
+    print(json.dumps(measure(parse())))
 
 
 if __name__ == "__main__":

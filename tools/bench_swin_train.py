@@ -56,7 +56,7 @@ def cpu_baseline(encoder: str, channels: int, tile: int, budget_s: float = 20.0,
             "sample": f"{n} timed step(s) of batch {B} after 1 warm-up, oracle/swin_upernet.py (fp32 eager torch, AdamW)"}
 
 
-def main():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--arch", default="swin_tiny_patch4_window7_224-upernet")
     ap.add_argument("--batch", type=int, default=32)
@@ -66,7 +66,11 @@ def main():
     ap.add_argument("--channels", type=int, default=5)
     ap.add_argument("--graph", action="store_true", help="capture the step as one hipGraph (GraphedTrainStep)")
     ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU oracle's step (about 20-40 s)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def measure(args) -> dict:
+    """one measurement; also called in-process by bench.py (extra object "swin_t" of the driver-run line)"""
     from flairhip.configs import unet_resnet34_config
     from flair_hub.tasks.module_setup import build_segmentation_module
     MOD, TASK = "AERIAL_RGBI", "AERIAL_LABEL-COSIA"
@@ -154,13 +158,17 @@ def main():
     cpu = None
     if args.cpu_baseline:
         cpu = cpu_baseline(args.arch.split("-")[0], args.channels, S)
-    print(json.dumps({
+    return ({
         "roofline": roofline, "cpu_baseline": cpu,
         "metric": f"{S}x{S}x{args.channels} tiles/sec (train fwd+bwd+AdamW), {args.arch}, 19 classes",
         "value": round(B * args.steps / dt, 1), "unit": "tiles/s", "ms_per_step": round(dt / args.steps * 1e3, 2),
         "batch": B, "dtype": "bf16", "mode": "hipGraph" if graphed is not None else "eager",
         "parameters": nparams, "loss": round(float(loss.detach()), 4), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
-        "data": "synthetic"}))
+        "data": "synthetic"})
+
+
+def main():
+    print(json.dumps(measure(parse())))
 
 
 if __name__ == "__main__":
