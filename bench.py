@@ -75,7 +75,9 @@ class KernelTimer:
             flops = 2.0 * B * (Ho * Wo / (dil * dil)) * w.rows_real * w.ch_real * w.kh * w.kw
             tile = "8x32" if Wo >= 32 else "16x16"
             dt = "bf16" if x.dtype == torch.bfloat16 else "f32"
-            if w.bco & 0x1000:  # ring-layout operand: conv3x3_ring16_kernel (bf16, the default) / conv3x3_ring_kernel (f32)
+            if w.bco & 0x2000:  # thin-layout operand: conv3x3_thin_kernel (<= 32 channels in, <= 32 rows)
+                sym = f"conv3x3_thin_kernel<bf16,ci{w.ci_pitch},rows{w.rows}>"
+            elif w.bco & 0x1000:  # ring-layout operand: conv3x3_ring16_kernel (bf16, the default) / conv3x3_ring_kernel (f32)
                 sym = (f"conv3x3_ring16_kernel<bf16,co64,{tile}>" if dt == "bf16"
                        else f"conv3x3_ring_kernel<{dt},{tile}{_hk_tag(w, x.dtype)}>")
             elif ops.conv_is_persistent(x.dtype, B, Ho, Wo, w, dil):  # blocks walking several tiles: its own symbol
@@ -115,6 +117,8 @@ class KernelTimer:
                 B, H, W = dy.shape[0], dy.shape[1], dy.shape[2]
                 dt = "bf16" if dy.dtype == torch.bfloat16 else "f32"
                 sym = f"conv_igemm_kernel<{dt},3x3,s1,bco{wt.bco},{'8x32' if W >= 32 else '16x16'}{_hk_tag(wt, dy.dtype)}>"
+                if wt.bco & 0x2000:
+                    sym = f"conv3x3_thin_kernel<bf16,ci{wt.ci_pitch},rows{wt.rows},pool>"
                 timer.records.append((sym, 2.0 * B * H * W * wt.rows_real * wt.ch_real * 9, s, e))
             return r
 
@@ -130,6 +134,8 @@ class KernelTimer:
                 B, H, W = y.shape[0], y.shape[1], y.shape[2]
                 dt = "bf16" if lo.dtype == torch.bfloat16 else "f32"
                 sym = f"conv_igemm_kernel<{dt},3x3,s1,bco{w.bco},{'8x32' if W >= 32 else '16x16'}{_hk_tag(w, lo.dtype)},up>"
+                if w.bco & 0x2000:
+                    sym = f"conv3x3_thin_kernel<bf16,ci{w.ci_pitch},rows{w.rows},up>"
                 timer.records.append((sym, 2.0 * B * H * W * w.rows_real * w.ch_real * 9, s, e))
             return y
 

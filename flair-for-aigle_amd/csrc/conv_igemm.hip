@@ -1198,6 +1198,15 @@ extern "C" int ffa_ring_conv3x3(int dtype, const void* in, const void* w_ring, c
 extern "C" int ffa_ring_pack(int dtype, const float* w_oihw, const float* scale, void* dst, int O, int I, int transpose,
                              int co_rows, int ci_pitch, hipStream_t stream);
 
+// thin kernel entry points (conv3x3_thin.hip)
+extern "C" int ffa_thin_eligible(int dtype, int kh, int kw, int stride, int rows_real, int ci_pitch);
+extern "C" long long ffa_thin_stat_rows(int B, int H, int W, int ci_pitch);
+extern "C" int ffa_thin_conv3x3(const void* in, const void* w_thin, const float* bias, const void* residual, void* out,
+                                float* stat_partials, int B, int H, int W, int Ci, int Co, int co_rows, int relu, int up,
+                                int pool, hipStream_t stream);
+extern "C" int ffa_thin_pack(const float* w_oihw, const float* scale, void* dst, int O, int I, int transpose, int co_rows,
+                             int ci_pitch, hipStream_t stream);
+
 // Operand layout + block height for a layer: the value to hand to ffa_pack_conv_weight / ffa_conv2d as `bco`.
 // Bits 0..11 = rows per block (the padded row count is a multiple of it); FFA_BCO_RING set = the operand is packed
 // for the ring kernels of conv3x3_ring.hip (3x3 stride 1 pad 1, >= 64 rows, whole 64-byte groups of input channels;
@@ -1207,9 +1216,18 @@ extern "C" int ffa_ring_pack(int dtype, const float* w_oihw, const float* scale,
 //         36 / 32.5 / 34.7 us on the 128 / 256 / 512-channel layers against 40 / 37.3 / 38 for conv3x3_persist_kernel
 //         (same box); FFA_RING=0 restores the conv_igemm operands;
 //   f32:  conv3x3_ring_kernel only with FFA_RING=1 (it equals the persist kernel).
+// allow_ring bit 1 (value 2): the caller can also take FFA_BCO_THIN -- conv3x3_thin_kernel for bf16 layers with at most
+// 32 stored input channels and 32 rows (plain, statistics, two-source with C2 = 0 and pooled-split with C2 = 0 calls;
+// not the zero-insertion or the BatchNorm-backward-partials forms); rows per block 16 or 32.  FFA_THIN=0 disables.
 extern "C" int ffa_conv_plan(int dtype, int kh, int kw, int stride, int cout, int ci_pitch, int allow_ring) {
   const int bco = ffa_conv_block_co(kh, kw, stride, cout);
   if (bco < 0) return bco;
+  {
+    const char* t = getenv("FFA_THIN");
+    if ((allow_ring & 2) && !(t && t[0] == '0') && ffa_thin_eligible(dtype, kh, kw, stride, cout, ci_pitch))
+      return (cout <= 16 ? 16 : 32) | FFA_BCO_THIN | (ci_pitch == 32 ? FFA_BCO_THIN32 : 0);
+  }
+  allow_ring &= 1;
   const char* e = getenv("FFA_RING");
   const int eb = (dtype == FFA_BF16) ? 2 : 4;
   const bool on = (dtype == FFA_BF16) ? !(e && e[0] == '0') : (e && e[0] == '1');
@@ -1233,6 +1251,17 @@ static int conv2d_impl(int dtype, const void* in, const void* w_packed, const fl
   FFA_REQUIRE(dil == 1 || stride == 1, "conv: zero-insertion input needs stride 1");
   FFA_REQUIRE((long long)B * Hi * Wi * Ci * (dtype == FFA_BF16 ? 2 : 4) < (1LL << 31),
               "conv: input tensor must be smaller than 2 GiB (32-bit piece offsets)");
+  if (bco & FFA_BCO_THIN) {
+    FFA_REQUIRE(dtype == FFA_BF16 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && Hi == Ho && Wi == Wo &&
+                    bnx == nullptr,
+                "conv: a thin-layout operand serves bf16 3x3 stride-1 pad-1 convolutions only");
+    if (c1_out > 0) {  // pooled split epilogue: only the all-low-resolution form (no skip part)
+      FFA_REQUIRE(c1_out == Co && out2 == nullptr && !stat_partials, "conv: thin pooled form takes C2 = 0 only");
+      return ffa_thin_conv3x3(in, w_packed, nullptr, nullptr, out, nullptr, B, Hi, Wi, Ci, Co, co_rows, 0, 0, 1, stream);
+    }
+    return ffa_thin_conv3x3(in, w_packed, bias, residual, out, stat_partials, B, Hi, Wi, Ci, Co, co_rows, relu, 0, 0,
+                            stream);
+  }
   if (bco & FFA_BCO_RING) {
     FFA_REQUIRE(kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && Hi == Ho && Wi == Wo && c1_out == 0 &&
                     bnx == nullptr,
@@ -1305,6 +1334,7 @@ static long long conv_stat_rows_igemm(int B, int Ho, int Wo) {
 // co_rows / bco: the operand the convolution will run with (ffa_conv_plan); the row count is the number of pixel
 // tiles of the kernel that serves it
 extern "C" long long ffa_conv_stat_rows(int B, int Ho, int Wo, int co_rows, int bco) {
+  if (bco & FFA_BCO_THIN) return ffa_thin_stat_rows(B, Ho, Wo, (bco & FFA_BCO_THIN32) ? 32 : 16);
   if (bco & FFA_BCO_RING) return ffa_ring_stat_rows(B, Ho, Wo, co_rows);
   return conv_stat_rows_igemm(B, Ho, Wo);
 }
@@ -1316,7 +1346,7 @@ extern "C" int ffa_conv_is_persistent(int dtype, int B, int Ho, int Wo, int Ci, 
   if (!(kh == 3 && kw == 3 && stride == 1) || bco <= 0 || co_rows % bco != 0) return 0;
   const int nchunks = Ci * (dtype == FFA_BF16 ? 2 : 4) / 32;
   if (nchunks % 2 != 0) return 0;  // HK = 1 instantiations have no pipelined path
-  if (bco & FFA_BCO_RING) return 0;
+  if (bco & (FFA_BCO_RING | FFA_BCO_THIN)) return 0;
   const int npt = (int)conv_stat_rows_igemm(B, Ho, Wo);
   return conv_persist_grid(dil, 0, nullptr, ffa_cdiv(npt, 8) * 8 * (co_rows / bco)) > 0 ? 1 : 0;
 }
@@ -1348,6 +1378,13 @@ extern "C" int ffa_conv2d_upcat(int dtype, const void* lo, const void* skip, con
               "conv_upcat: bad dims");
   const int eb = (dtype == FFA_BF16) ? 2 : 4;
   const int Hi = 2 * Hl, Wi = 2 * Wl, Ci = C1 + C2;
+  if (bco & FFA_BCO_THIN) {
+    if (C2 != 0 || dtype != FFA_BF16) {
+      ffa_set_error("conv_upcat: a thin-layout operand takes the skip-less form only");
+      return FFA_ERR_UNSUPPORTED;
+    }
+    return ffa_thin_conv3x3(lo, w_packed, bias, nullptr, out, stat_partials, B, Hi, Wi, C1, Co, co_rows, relu, 1, 0, stream);
+  }
   FFA_REQUIRE((long long)B * Hi * Wi * (C1 > C2 ? C1 : C2) * eb < (1LL << 31),
               "conv_upcat: source tensors must be smaller than 2 GiB (32-bit piece offsets)");
   if (!conv_supported(3, 3, 1, bco) || co_rows % bco != 0) {
@@ -1399,6 +1436,14 @@ extern "C" int ffa_conv2d_dgrad_upcat(int dtype, const void* dy, const void* w_p
                                       hipStream_t stream) {
   FFA_REQUIRE(dy && w_packed_t && dlo && (dskip || C2 == 0), "dgrad_upcat: null pointer");
   FFA_REQUIRE(Ho % 2 == 0 && Wo % 2 == 0 && C1 > 0 && C2 >= 0 && C1 % 8 == 0 && C2 % 8 == 0, "dgrad_upcat: bad dims");
+  if (bco & FFA_BCO_THIN) {
+    if (C2 != 0) {
+      ffa_set_error("dgrad_upcat: a thin-layout operand takes the skip-less form only");
+      return FFA_ERR_UNSUPPORTED;
+    }
+    return conv2d_impl(dtype, dy, w_packed_t, nullptr, nullptr, dlo, nullptr, B, Ho, Wo, Cdy, Ho, Wo, C1, co_rows, bco, 3,
+                       3, 1, 1, 1, 0, stream, nullptr, C1);
+  }
   if (C1 % bco != 0) {
     ffa_set_error("dgrad_upcat: C1 = %d is not a multiple of the %d-row block", C1, bco);
     return FFA_ERR_UNSUPPORTED;
@@ -1473,6 +1518,10 @@ extern "C" int ffa_pack_conv_weight(int dtype, const float* w_oihw, const float*
                                     hipStream_t stream) {
   FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "pack: bad dtype");
   FFA_REQUIRE(w_oihw && dst, "pack: null pointer");
+  if (bco & FFA_BCO_THIN) {
+    FFA_REQUIRE(kh == 3 && kw == 3 && dtype == FFA_BF16, "pack: the thin layout is for bf16 3x3 kernels");
+    return ffa_thin_pack(w_oihw, scale, dst, O, I, transpose, co_rows, ci_pitch, stream);
+  }
   if (bco & FFA_BCO_RING) {
     FFA_REQUIRE(kh == 3 && kw == 3, "pack: the ring layout is for 3x3 kernels");
     return ffa_ring_pack(dtype, w_oihw, scale, dst, O, I, transpose, co_rows, ci_pitch, stream);

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("FLAIRHIP_LIB") or os.path.join(_HERE, "libflairhip.so
 BF16 = 0
 F32 = 1
 BCO_RING = 0x1000  # FFA_BCO_RING
+BCO_THIN = 0x2000  # FFA_BCO_THIN
 ERR_UNSUPPORTED = -2  # FFA_ERR_UNSUPPORTED: no kernel for the requested shape (callers may fall back to another op)
 
 
@@ -56,6 +57,10 @@ SIGNATURES = {
     "ffa_ring_conv3x3": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
     "ffa_ring_stat_rows": (_ll, [_i, _i, _i, _i]),
     "ffa_ring_pack": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "ffa_thin_pack_bytes": (_ll, [_i, _i]),
+    "ffa_thin_pack_desc_bytes": (_i, []),
+    "ffa_thin_pack_desc_fill": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i]),
+    "ffa_thin_pack_batched": (_i, [_p, _i, _p]),
     "ffa_ring_pack_desc_bytes": (_i, []),
     "ffa_ring_pack_desc_fill": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i]),
     "ffa_ring_pack_batched": (_i, [_i, _p, _i, _p]),

@@ -56,12 +56,14 @@ class HipConv2d(nn.Module):
             self.out_channels)
 
     def packed(self, dtype: torch.dtype, transpose: bool = False, scale: Optional[torch.Tensor] = None,
-               tag: str = "", ring: bool = True) -> ops.PackedWeight:
+               tag: str = "", ring: bool = True, thin: bool = True) -> ops.PackedWeight:
         """MFMA operand for the current weight values; re-packed only when the parameter changed.  ring=False keeps
-        the conv_igemm layout (operands of the two-source / split-epilogue / bn-backward-epilogue kernels)."""
+        the conv_igemm layout (operands of the two-source / split-epilogue / bn-backward-epilogue kernels); thin=False
+        keeps a <= 32-channel layer off conv3x3_thin_kernel (it has no BatchNorm-backward-partials epilogue)."""
         ring = ring and self.padding == 1  # the ring kernel is a pad-1 kernel
-        if not ring and not tag:
-            tag = "igemm"
+        thin = thin and self.padding == 1
+        if not tag:
+            tag = "plain" if not thin else ("" if ring else "igemm")
         key = (dtype, transpose, tag)
         ver = (self.weight._version, self.weight.data_ptr(), None if scale is None else scale._version, _STATE_EPOCH)
         hit = self._cache.get(key)
@@ -71,7 +73,8 @@ class HipConv2d(nn.Module):
         if not w.is_contiguous():
             w = w.contiguous()
         pitch = self.out_pitch if transpose else self.in_pitch
-        pw = ops.pack_conv_weight(w, dtype, self.stride, pitch, transpose=transpose, scale=scale, allow_ring=ring)
+        pw = ops.pack_conv_weight(w, dtype, self.stride, pitch, transpose=transpose, scale=scale, allow_ring=ring,
+                                  allow_thin=thin)
         self._cache[key] = (ver, pw)
         return pw
 
@@ -123,7 +126,7 @@ class PackPlan:
         entries, sig, slots = [], [], []
         for c in self.convs:
             for transpose in (False, True):
-                for tag in ("", "igemm"):
+                for tag in ("", "igemm", "plain"):
                     hit = c._cache.get((dtype, transpose, tag))
                     if hit is None:
                         continue
@@ -291,7 +294,7 @@ class _DecoderBlock(torch.autograd.Function):
         db_, _, dgb, dbb = ops.bn_bwd(xb, _as_nhwc_grad(dy), None, gb, bb, mb, rb, True, False)
         dwb = (ops.conv_wgrad(ya, db_, cb.out_channels, cb.in_channels, 3, 3, 1, 1, out=_dw_out(cb))
                if ctx.needs_input_grad[5] else None)
-        pbt = cb.packed(db_.dtype, transpose=True, ring=not ops.FUSED_BN_BWD)
+        pbt = cb.packed(db_.dtype, transpose=True, ring=not ops.FUSED_BN_BWD, thin=not ops.FUSED_BN_BWD)
         if ops.FUSED_BN_BWD:
             dya, part, rows = ops.conv2d_bnbwd(db_, pbt, 1, ya.shape[-1], xa, sca, sha)
             da, dga, dba = ops.bn_bwd_partials(xa, dya, part, rows, ga, ba, ma, ra)
@@ -371,7 +374,7 @@ class _BasicBlock(torch.autograd.Function):
         dw2 = wgrad(c2, y1, d2) if ctx.needs_input_grad[4] else None
         if ops.FUSED_BN_BWD:
             # bn1's backward reductions come out of conv2's dgrad epilogue (one pass over x1 and dy1 fewer)
-            dy1, part, rows = ops.conv2d_bnbwd(d2, c2.packed(d2.dtype, transpose=True, ring=False), c2.kernel_size - 1 - c2.padding,
+            dy1, part, rows = ops.conv2d_bnbwd(d2, c2.packed(d2.dtype, transpose=True, ring=False, thin=False), c2.kernel_size - 1 - c2.padding,
                                                y1.shape[-1], x1, sc1, sh1)
             d1, dg1, db1 = ops.bn_bwd_partials(x1, dy1, part, rows, g1, b1, m1, r1)
         else:

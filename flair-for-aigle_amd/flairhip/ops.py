@@ -86,10 +86,12 @@ class PackedWeight:
 
 def pack_conv_weight(w_oihw: torch.Tensor, dtype: torch.dtype, stride: int, ci_pitch: int,
                      transpose: bool = False, scale: Optional[torch.Tensor] = None,
-                     allow_ring: bool = True) -> PackedWeight:
+                     allow_ring: bool = True, allow_thin: bool = True) -> PackedWeight:
     """OIHW f32 master weight -> MFMA operand for ffa_conv2d (forward, or dgrad when transpose=True).
     allow_ring=False keeps the operand in the conv_igemm layout (needed by the two-source / split-epilogue /
-    zero-insertion calls); otherwise ffa_conv_plan picks the LDS-DMA ring layout where it applies."""
+    zero-insertion calls); otherwise ffa_conv_plan picks the LDS-DMA ring layout where it applies.  allow_thin:
+    bf16 layers with at most 32 stored input channels and 32 rows may get the register-resident layout of
+    conv3x3_thin_kernel (plain, statistics, skip-less two-source and skip-less pooled-split calls)."""
     lib = _l.load()
     if w_oihw.dtype != torch.float32 or not w_oihw.is_contiguous():
         raise ValueError("pack_conv_weight: master weight must be contiguous f32 OIHW")
@@ -99,13 +101,16 @@ def pack_conv_weight(w_oihw: torch.Tensor, dtype: torch.dtype, stride: int, ci_p
     did = _dtype_id(dtype)
     # the dgrad operand of a stride-2 layer is read through the zero insertion (dil = 2): conv_igemm only
     ring_ok = allow_ring and not (transpose and stride != 1)
-    bco = lib.ffa_conv_plan(did, kh, kw, use_stride, rows_real, ci_pitch, 1 if ring_ok else 0)
+    thin_ok = allow_thin and not (transpose and stride != 1)
+    bco = lib.ffa_conv_plan(did, kh, kw, use_stride, rows_real, ci_pitch, (1 if ring_ok else 0) | (2 if thin_ok else 0))
     if bco <= 0:
         raise _l.FlairHipError(f"no conv kernel for {kh}x{kw} stride {use_stride}")
     blk = bco & 0xFFF
     rows = (rows_real + blk - 1) // blk * blk
     rg = lib.ffa_conv_row_group(kh)
     nbytes = lib.ffa_pack_conv_weight_bytes(did, rows, ci_pitch, kh, kw)
+    if bco & _l.BCO_THIN:
+        nbytes = lib.ffa_thin_pack_bytes(rows, ci_pitch)
     dst = torch.empty(nbytes // (2 if dtype == torch.bfloat16 else 4), dtype=dtype, device=w_oihw.device)
     _l.check(lib.ffa_pack_conv_weight(did, w_oihw.data_ptr(), _ptr(scale), dst.data_ptr(), O, I, kh, kw,
                                       1 if transpose else 0, rows, ci_pitch, bco, rg, _stream()), "pack_conv_weight")
@@ -123,10 +128,12 @@ class PackBatch:
         lib = _l.load()
         self.dtype_id = _dtype_id(dtype)
         self.keep = []
-        plain = [e for e in entries if not (e[1].bco & _l.BCO_RING)]
+        plain = [e for e in entries if not (e[1].bco & (_l.BCO_RING | _l.BCO_THIN))]
         ring = [e for e in entries if e[1].bco & _l.BCO_RING]
+        thin = [e for e in entries if e[1].bco & _l.BCO_THIN]
         self.n, self.table = len(plain), None
         self.n_ring, self.table_ring = len(ring), None
+        self.n_thin, self.table_thin = len(thin), None
         dev = entries[0][0].device
         if plain:
             nb = lib.ffa_pack_desc_bytes()
@@ -150,6 +157,16 @@ class PackBatch:
                          "ring_pack_desc_fill")
                 self.keep.append((w, pw))
             self.table_ring = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
+        if thin:
+            nb = lib.ffa_thin_pack_desc_bytes()
+            host = C.create_string_buffer(nb * len(thin))
+            base = C.addressof(host)
+            for i, (w, pw, transpose) in enumerate(thin):
+                O, I, kh, kw = w.shape
+                _l.check(lib.ffa_thin_pack_desc_fill(base + i * nb, w.data_ptr(), None, pw.data.data_ptr(), O, I,
+                                                     1 if transpose else 0, pw.rows, pw.ci_pitch), "thin_pack_desc_fill")
+                self.keep.append((w, pw))
+            self.table_thin = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
 
     def run(self) -> None:
         lib = _l.load()
@@ -159,6 +176,8 @@ class PackBatch:
         if self.table_ring is not None:
             _l.check(lib.ffa_ring_pack_batched(self.dtype_id, self.table_ring.data_ptr(), self.n_ring, _stream()),
                      "ring_pack_batched")
+        if self.table_thin is not None:
+            _l.check(lib.ffa_thin_pack_batched(self.table_thin.data_ptr(), self.n_thin, _stream()), "thin_pack_batched")
 
 
 def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:
@@ -390,7 +409,7 @@ def conv2d_upcat_bn_stats(lo: torch.Tensor, skip: Optional[torch.Tensor], w: Pac
     """conv2d_upcat + batch statistics of its output -> (y0, scale, shift, mean, rstd)"""
     B, Hl, Wl, _ = lo.shape
     Ho, Wo = 2 * Hl, 2 * Wl
-    rows = conv_stat_rows(B, Ho, Wo)
+    rows = conv_stat_rows(B, Ho, Wo, w)
     part = workspace(rows * 2 * out_channels * 4, lo.device, "bnpart").view(torch.float32)
     y0 = conv2d_upcat(lo, skip, w, out_channels, stats=part)
     if y0 is None:

@@ -636,7 +636,7 @@ def test_bn_backward_reductions_from_dgrad_epilogue(cuda, dtype, cin, cout, H, W
     cip, cop = ops.pad_channels(cin), ops.pad_channels(cout)
     d2 = to_nhwc(torch.randn(B, cin, H, W, generator=g), dtype, cuda, cip)          # incoming gradient
     w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(cuda)      # acts as the dgrad operand
-    pw = ops.pack_conv_weight(w, dtype, 1, cip, allow_ring=False)
+    pw = ops.pack_conv_weight(w, dtype, 1, cip, allow_ring=False, allow_thin=False)
     x1 = to_nhwc(torch.randn(B, cout, H, W, generator=g), dtype, cuda, cop)          # pre-norm tensor of the BN
     gamma = (torch.rand(cop, generator=g) + 0.5).to(cuda)
     beta = (torch.randn(cop, generator=g) * 0.3).to(cuda)

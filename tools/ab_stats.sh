@@ -10,6 +10,6 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o r -- \
-    python3 "$R/bench.py" --no-cpu-baseline > "$OUT/bench_stats.log" 2>&1
+    python3 "$R/bench.py" --no-cpu-baseline --no-extras > "$OUT/bench_stats.log" 2>&1
 rm -f "$OUT"/stats/*/r_kernel_trace.csv "$OUT"/stats/r_kernel_trace.csv
 python3 "$R/tools/stats_per_step.py" "$OUT" > "$OUT/per_step.txt"
