@@ -874,13 +874,256 @@ wgrad_reduce3x3_kernel(const float* __restrict__ slabs, float* __restrict__ dw, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Thin layers (bf16, 3x3 stride 1 pad 1, <= 32 stored channels on BOTH sides: the U-Net decoder tail and head; round 3).
+// conv_wgrad_kernel pads their 16-channel operands to 32 x 32 MFMA tiles (a 16 x 16 layer issues four times its
+// matrix work: 18 MFMA cycles per pixel and SIMD, which is what the HBM rate allows -- the kernel sat at 55-60 % of its
+// byte floor).  Here:
+//   * v_mfma_f32_16x16x32_bf16: exact 16-channel tiles, K = 32 pixels = one row of the 8 x 32 tile; every wave owns
+//     ALL (co, ci, tap) tiles of the layer (36 ... 144 accumulator registers) and two rows of each spatial tile -- no
+//     channel split, no operand re-read;
+//   * both operands keep their natural [pixel][channels] form in LDS and the K-contiguous fragments come out of
+//     ds_read_b64_tr_b16 (two reads of 4 pixels x 16 channels per fragment; the nine tap shifts are address offsets);
+//   * x halo + dy tile arrive by LDS-DMA (zero page for the padding / ragged edges, nearest-x2 source for the
+//     decoder's upsampled input), one or two tiles ahead of the tile being multiplied; no stores in the loop, so the
+//     vmcnt arithmetic is exact;
+//   * the four waves are summed through LDS in a fixed order and ONE f32 slab per block goes to the split-K workspace
+//     (wgrad_reduce_kernel finishes: deterministic, no float atomics).
+
+__device__ __attribute__((aligned(16))) const unsigned int ffa_wgthin_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void wgthin_dma16(const unsigned char* src, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_base)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wgthin_wait_and_meet() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(N) : "memory");
+}
+
+template <int CI, int CO>
+struct WgThinGeom {
+  static constexpr int TH = 8, TW = 32;
+  static constexpr int IH = TH + 2, IW = TW + 2;
+  static constexpr int XB = CI * 2, YB = CO * 2;  // bytes per pixel
+  static constexpr int XP = IH * IW * (XB / 16);  // 16-byte pieces of the x halo
+  static constexpr int YP = TH * TW * (YB / 16);  // ... of the dy tile (follows the halo in the slot)
+  static constexpr int PIECES = XP + YP;
+  static constexpr int NHW = (PIECES + 255) / 256;
+  static constexpr int X_BYTES = XP * 16;
+  static constexpr int SLOT = PIECES * 16;
+  static constexpr int NSLOT = (3 * SLOT <= 78 * 1024) ? 3 : 2;
+  static constexpr int MT = CO / 16, NT = CI / 16;
+  static constexpr int ACC_BYTES = MT * NT * 9 * 4 * 64 * 4;  // one wave's accumulators
+  static constexpr int LDS_BYTES = (NSLOT * SLOT > 2 * ACC_BYTES) ? NSLOT * SLOT : 2 * ACC_BYTES;
+  static_assert(2 * LDS_BYTES <= 160 * 1024, "two blocks per CU");
+};
+
+template <int CI, int CO, bool UP>
+__global__ void __launch_bounds__(256, 2) conv3x3_thin_wgrad_kernel(WgradArgs a) {
+  using G = WgThinGeom<CI, CO>;
+  constexpr int MT = G::MT, NT = G::NT;
+  __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15;  // fragment row (co) / column (ci); address role: pixel li >> 2, 8-byte segment li & 3
+  const int kg = lane >> 4;  // pixels 8*kg .. 8*kg+7 of a 32-pixel k-step
+
+  // ---- pieces of this thread: p = tid + k * 256; p < XP: halo pixel p / (XB/16) of x, else pixel of the dy tile ----
+  int pinfo[G::NHW];  // x: (hy << 8 | hx) << 4 | slot;  dy: 1 << 30 | (ry << 8 | rx) << 4 | slot;  -1: no piece
+#pragma unroll
+  for (int k = 0; k < G::NHW; ++k) {
+    const int p = tid + k * 256;
+    if (p < G::XP) {
+      const int q = p / (G::XB / 16), sl = p % (G::XB / 16);
+      pinfo[k] = ((((q / G::IW) << 8) | (q % G::IW)) << 4) | sl;
+    } else if (p < G::PIECES) {
+      const int j = p - G::XP;
+      const int q = j / (G::YB / 16), sl = j % (G::YB / 16);
+      pinfo[k] = (1 << 30) | ((((q / G::TW) << 8) | (q % G::TW)) << 4) | sl;
+    } else {
+      pinfo[k] = -1;
+    }
+  }
+  const unsigned char* x_b = static_cast<const unsigned char*>(a.x);
+  const unsigned char* dy_b = static_cast<const unsigned char*>(a.dy);
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(ffa_wgthin_zero16);
+  const int Hs = UP ? (a.Hi >> 1) : a.Hi, Ws = UP ? (a.Wi >> 1) : a.Wi;
+  const bool has_tail = (G::PIECES % 256 == 0) || (wave * 64 + (G::NHW - 1) * 256 < G::PIECES);
+
+  auto tile_origin = [&](int t, int& b, int& oy0, int& ox0) {
+    const int tx = t % a.tiles_x;
+    const int t2 = t / a.tiles_x;
+    oy0 = (t2 % a.tiles_y) * G::TH;
+    b = t2 / a.tiles_y;
+    ox0 = tx * G::TW;
+  };
+  auto issue_tile = [&](int t, int slot) {
+    int b, oy0, ox0;
+    tile_origin(t, b, oy0, ox0);
+#pragma unroll
+    for (int k = 0; k < G::NHW; ++k) {
+      const int info = pinfo[k];
+      const int yy = (info >> 12) & 0xff, xx = (info >> 4) & 0xff, sl = info & 15;
+      const unsigned char* src = zero;
+      if (info >= 0) {
+        if (info & (1 << 30)) {
+          const int oy = oy0 + yy, ox = ox0 + xx;
+          if (oy < a.Ho && ox < a.Wo) src = dy_b + ((size_t)((b * a.Ho + oy) * a.Wo + ox) * G::YB + sl * 16);
+        } else {
+          const int vy = oy0 - 1 + yy, vx = ox0 - 1 + xx;
+          if (vy >= 0 && vx >= 0 && vy < a.Hi && vx < a.Wi) {
+            const int sy = UP ? (vy >> 1) : vy, sx = UP ? (vx >> 1) : vx;
+            src = x_b + ((size_t)((b * Hs + sy) * Ws + sx) * G::XB + sl * 16);
+          }
+        }
+      }
+      const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(
+          smem + slot * G::SLOT + (wave * 64 + k * 256) * 16);
+      if (k + 1 < G::NHW || G::PIECES % 256 == 0) {
+        wgthin_dma16(src, dst);
+      } else if (has_tail) {
+        if (info >= 0) wgthin_dma16(src, dst);
+      }
+    }
+  };
+  // wait until this wave's fill of the CURRENT tile has landed: with a three-slot ring one younger fill may stay in
+  // flight, with two slots nothing younger exists at this point
+  auto wait_tile = [&]() {
+    if constexpr (G::NSLOT == 3) {
+      if (has_tail) wgthin_wait_and_meet<G::NHW>();
+      else wgthin_wait_and_meet<G::NHW - 1>();
+    } else {
+      wgthin_wait_and_meet<0>();
+    }
+  };
+
+  ffa_f32x4 acc[MT][NT][9];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) acc[mt][nt][tp] = ffa_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane fragment bases: pixel 8*kg + (li >> 2) of a k-step, 8-byte segment li & 3 of a 16-channel group; the
+  // wave's first tile row is 2 * wave (two rows per wave)
+  const int px0 = 8 * kg + (li >> 2);
+  const int aBase = G::X_BYTES + ((2 * wave) * G::TW + px0) * G::YB + (li & 3) * 8;
+  const int bBase = ((2 * wave) * G::IW + px0) * G::XB + (li & 3) * 8;
+
+  auto tr2 = [&](const unsigned char* p0, int step) {
+    const ffa_s16x4 v0 = lds_read_tr16(p0);
+    const ffa_s16x4 v1 = lds_read_tr16(p0 + step);
+    ffa_u32x4 f;
+    f.x = __builtin_bit_cast(ffa_u32x2, v0).x;
+    f.y = __builtin_bit_cast(ffa_u32x2, v0).y;
+    f.z = __builtin_bit_cast(ffa_u32x2, v1).x;
+    f.w = __builtin_bit_cast(ffa_u32x2, v1).y;
+    return f;
+  };
+
+  int t = blockIdx.x;
+  const int stride = gridDim.x;
+  if (t < a.npt) {
+    issue_tile(t, 0);
+    if constexpr (G::NSLOT == 3) issue_tile(t + stride < a.npt ? t + stride : t, 1);
+    int slot = 0;
+    for (; t < a.npt; t += stride) {
+      wait_tile();
+      {
+        const int tn = t + (G::NSLOT - 1) * stride;
+        issue_tile(tn < a.npt ? tn : t, (slot + G::NSLOT - 1) % G::NSLOT);
+      }
+      const unsigned char* sS = smem + slot * G::SLOT;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {  // the wave's two rows = two k-steps of 32 pixels
+        ffa_u32x4 af[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = tr2(sS + aBase + rr * G::TW * G::YB + mt * 32, 4 * G::YB);
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const ffa_u32x4 bf = tr2(sS + bBase + ((rr + tp / 3) * G::IW + tp % 3) * G::XB + nt * 32, 4 * G::XB);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              acc[mt][nt][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ffa_bf16x8, af[mt]),
+                                                                       __builtin_bit_cast(ffa_bf16x8, bf), acc[mt][nt][tp],
+                                                                       0, 0, 0);
+          }
+        }
+      }
+      slot = (slot + 1) % G::NSLOT;
+    }
+  }
+  // every DMA (also the fills for tiles that do not exist) has landed before the slots become reduction scratch
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // ---- sum the four waves in a fixed order: (0 + 2) and (1 + 3), then (0 + 1) ----
+  float* red = reinterpret_cast<float*>(smem);
+  constexpr int NACC = MT * NT * 9 * 4;  // floats per lane
+  auto put = [&](int which) {
+    float* dst = red + (size_t)which * NACC * 64 + lane;
+    int o = 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dst[(o++) * 64] = acc[mt][nt][tp][i];
+  };
+  auto add = [&](int which) {
+    const float* src = red + (size_t)which * NACC * 64 + lane;
+    int o = 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[mt][nt][tp][i] += src[(o++) * 64];
+  };
+  if (wave >= 2) put(wave - 2);
+  __syncthreads();
+  if (wave < 2) add(wave);
+  __syncthreads();
+  if (wave == 1) put(0);
+  __syncthreads();
+  if (wave != 0) return;
+  add(0);
+
+  // ---- the block's slab [CoT][9][CiT]: D[row = co][col = ci], lane (li = ci, rows 4*kg + i) ----
+  float* slab = a.slabs + (size_t)blockIdx.x * a.CoT * 9 * a.CiT;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int co = mt * 16 + 4 * kg + i, ci = nt * 16 + li;
+          slab[((size_t)co * 9 + tp) * a.CiT + ci] = acc[mt][nt][tp][i];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 
 struct WgradPlan {
-  int wco, wci, wk, th, tw, rg, nsplit, ncob, ncib, CoT, CiT, npt, tiles_x, tiles_y, ring, nslab, stem;
+  int wco, wci, wk, th, tw, rg, nsplit, ncob, ncib, CoT, CiT, npt, tiles_x, tiles_y, ring, nslab, stem, thin;
 };
 
 static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, int B, int Ho, int Wo, WgradPlan* p,
-                       bool allow_ring = true) {
+                       bool allow_ring = true, bool allow_thin = true) {
   const bool s1 = (kh == 3 && kw == 3 && stride == 1);
   const bool s2 = (kh == 3 && kw == 3 && stride == 2);
   const bool one = (kh == 1 && kw == 1 && (stride == 1 || stride == 2));
@@ -889,6 +1132,25 @@ static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, in
   const bool f32 = (dtype == FFA_F32);
   p->rg = stem ? 1 : kh;
   p->wk = 1;
+  p->thin = 0;
+  {
+    // conv3x3_thin_wgrad_kernel: bf16, 3x3 stride 1, channel pitches 16 or 32 on both sides (FFA_THIN_WGRAD=0 disables)
+    const char* tw_ = getenv("FFA_THIN_WGRAD");
+    if (allow_thin && s1 && !f32 && !(tw_ && tw_[0] == '0') && (Co == 16 || Co == 32) && (Ci == 16 || Ci == 32)) {
+      p->thin = 1;
+      p->th = 8; p->tw = 32;
+      p->wco = p->wci = 1;
+      p->ncob = p->ncib = 1;
+      p->CoT = Co; p->CiT = Ci;
+      p->tiles_x = ffa_cdiv(Wo, 32);
+      p->tiles_y = ffa_cdiv(Ho, 8);
+      p->npt = B * p->tiles_x * p->tiles_y;
+      p->ring = 0; p->stem = 0;
+      p->nsplit = p->npt < 512 ? p->npt : 512;  // persistent blocks, two per CU; one slab each
+      p->nslab = p->nsplit;
+      return true;
+    }
+  }
   if (s1) {
     p->tw = (Wo >= 32) ? 32 : 16;
     p->th = (Wo >= 32) ? 4 : 8;
@@ -963,9 +1225,15 @@ static bool wgrad_plan(int dtype, int kh, int kw, int stride, int Co, int Ci, in
 
 extern "C" long long ffa_conv_wgrad_workspace_bytes(int dtype, int kh, int kw, int stride, int Co, int Ci, int B, int Ho,
                                                     int Wo) {
-  WgradPlan p;
+  WgradPlan p, q;
   if (!wgrad_plan(dtype, kh, kw, stride, Co, Ci, B, Ho, Wo, &p)) return FFA_ERR_UNSUPPORTED;
-  return (long long)p.nslab * p.CoT * kh * kw * p.CiT * (long long)sizeof(float);
+  long long need = (long long)p.nslab * p.CoT * kh * kw * p.CiT * (long long)sizeof(float);
+  if (p.thin) {  // a two-source call with a real skip part falls back to conv_wgrad_kernel: size for either
+    wgrad_plan(dtype, kh, kw, stride, Co, Ci, B, Ho, Wo, &q, true, false);
+    const long long other = (long long)q.nslab * q.CoT * kh * kw * q.CiT * (long long)sizeof(float);
+    if (other > need) need = other;
+  }
+  return need;
 }
 
 template <typename T, int KH, int KW, int STRIDE, int RG, int WCO, int WCI, int WK, int TH, int TW>
@@ -980,6 +1248,22 @@ static int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int kh, int kw, 
   constexpr bool F32 = (sizeof(T) == 4);
   const bool wide = (p.tw == 32);
   if constexpr (!F32) {
+    if (p.thin) {
+      const bool up = a.C1 > 0;
+#define FFA_WGTHIN(CI_, CO_)                                                                                     \
+  if (a.Ci == CI_ && a.Co == CO_) {                                                                              \
+    if (up) hipLaunchKernelGGL((conv3x3_thin_wgrad_kernel<CI_, CO_, true>), dim3(a.nsplit), dim3(256), 0, stream, a);  \
+    else hipLaunchKernelGGL((conv3x3_thin_wgrad_kernel<CI_, CO_, false>), dim3(a.nsplit), dim3(256), 0, stream, a);    \
+    return ffa_check_launch("conv3x3_thin_wgrad");                                                               \
+  }
+      FFA_WGTHIN(16, 16)
+      FFA_WGTHIN(16, 32)
+      FFA_WGTHIN(32, 16)
+      FFA_WGTHIN(32, 32)
+#undef FFA_WGTHIN
+      ffa_set_error("conv_wgrad: no thin kernel for pitches %d / %d", a.Ci, a.Co);
+      return FFA_ERR_UNSUPPORTED;
+    }
     if (p.ring) {
       dim3 grid(a.ncob * a.ncib, a.nsplit);
       if (wide) hipLaunchKernelGGL((conv_wgrad_ring_kernel<4, 32>), grid, dim3(256), 0, stream, a);
@@ -1043,11 +1327,13 @@ static int wgrad_impl(int dtype, const void* x, const void* x2, int C1, const vo
   FFA_REQUIRE(Co_real <= Co && Ci_real <= Ci, "conv_wgrad: real channels exceed pitch");
   WgradPlan p;
   // the ring kernel's edge masks assume a one-pixel halo, and it has no two-source loader
-  if (!wgrad_plan(dtype, kh, kw, stride, Co, Ci, B, Ho, Wo, &p, pad == 1 && C1 == 0)) {
+  // the thin kernel reads one source: plain input, or the skip-less nearest-x2 form (C1 == Ci); pad-1 only
+  const bool thin_ok = pad == 1 && (C1 == 0 || (C1 == Ci && x2 == nullptr));
+  if (!wgrad_plan(dtype, kh, kw, stride, Co, Ci, B, Ho, Wo, &p, pad == 1 && C1 == 0, thin_ok)) {
     ffa_set_error("conv_wgrad: unsupported kernel %dx%d stride %d", kh, kw, stride);
     return FFA_ERR_UNSUPPORTED;
   }
-  if (C1 > 0) {
+  if (C1 > 0 && !p.thin) {
     if (C1 % (32 * p.wci) != 0) {
       ffa_set_error("conv_wgrad_upcat: C1 = %d is not a multiple of the block's %d input channels", C1, 32 * p.wci);
       return FFA_ERR_UNSUPPORTED;

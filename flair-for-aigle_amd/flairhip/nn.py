@@ -628,7 +628,7 @@ def _eval_folded(conv: HipConv2d, bn: HipBatchNorm2d, dtype: torch.dtype, ring: 
                                           bn.eps)
         w = conv.weight.detach()
         pw = ops.pack_conv_weight(w if w.is_contiguous() else w.contiguous(), dtype, conv.stride, conv.in_pitch,
-                                  scale=scale, allow_ring=ring)
+                                  scale=scale, allow_ring=ring and conv.padding == 1, allow_thin=conv.padding == 1)
         hit = (ver, pw, shift)
         conv._cache[ck] = hit
     return hit[1], hit[2]

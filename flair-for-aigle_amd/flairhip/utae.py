@@ -395,7 +395,8 @@ class HipUTAE(nn.Module):
         if bn is not None:
             scale, shift = ops.bn_eval_params(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                               bn.eps)
-        pw = ops.pack_conv_weight(w, self.dtype, 1, ci_pitch, transpose=transpose, scale=scale, allow_ring=False)
+        pw = ops.pack_conv_weight(w, self.dtype, 1, ci_pitch, transpose=transpose, scale=scale, allow_ring=False,
+                                  allow_thin=False)  # reflect-padded input, pad-0 convolution: conv_igemm only
         out_pitch = self._pitch(n_out)
         bias = torch.zeros(max(out_pitch, pw.rows), dtype=torch.float32, device=w.device)
         if with_bias:

@@ -129,3 +129,47 @@ def test_thin_two_source_and_pooled_forms(cuda, monkeypatch, c1, cout, Hl, Wl, c
     refl = F.avg_pool2d(dup, 2) * 4
     torch.cuda.synchronize()
     assert (from_nhwc(dlo, c1) - refl).abs().max().item() <= float(refl.abs().max()) * 2 ** -7
+
+
+WG_CASES = [(16, 16, 32, 64), (16, 16, 21, 45), (16, 19, 40, 40), (32, 32, 24, 40), (32, 16, 16, 96), (30, 30, 17, 33)]
+
+
+@pytest.mark.parametrize("cin,cout,H,W", WG_CASES, ids=[f"c{c[0]}-{c[1]}_{c[2]}x{c[3]}" for c in WG_CASES])
+def test_thin_wgrad_matches_torch_and_the_general_kernel(cuda, monkeypatch, cin, cout, H, W):
+    """conv3x3_thin_wgrad_kernel (16x16x32 MFMA on transposed LDS reads, LDS-DMA staging, one slab per persistent
+    block) against torch.nn.grad.conv2d_weight on the bf16-rounded operands and against conv_wgrad_kernel"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(cin * 5 + cout + W)
+    B = 3
+    x = torch.randn(B, cin, H, W, generator=g)
+    dy = torch.randn(B, cout, H, W, generator=g)
+    cip = ops.pad_channels(cin)
+    cop = 32 if cout == 19 else ops.pad_channels(cout)
+    xd, dyd = to_nhwc(x, cuda, cip), to_nhwc(dy, cuda, cop)
+    got = ops.conv_wgrad(xd, dyd, cout, cin, 3, 3, 1, 1)
+    monkeypatch.setenv("FFA_THIN_WGRAD", "0")
+    old = ops.conv_wgrad(xd, dyd, cout, cin, 3, 3, 1, 1)
+    ref = torch.nn.grad.conv2d_weight(rq(x), (cout, cin, 3, 3), rq(dy), padding=1)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    assert (got.cpu() - ref).abs().max().item() <= 2e-4 * scale * max(1.0, (B * H * W / 2000) ** 0.5)
+    assert (got - old).abs().max().item() <= 2e-4 * scale * max(1.0, (B * H * W / 2000) ** 0.5)
+    monkeypatch.delenv("FFA_THIN_WGRAD")
+    again = ops.conv_wgrad(xd, dyd, cout, cin, 3, 3, 1, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(got, again)  # fixed summation order
+
+
+def test_thin_wgrad_of_the_upsampled_input(cuda):
+    from flairhip import ops
+    g = torch.Generator().manual_seed(77)
+    B, c1, cout, Hl, Wl = 2, 32, 16, 20, 24
+    lo = torch.randn(B, c1, Hl, Wl, generator=g)
+    dy = torch.randn(B, cout, 2 * Hl, 2 * Wl, generator=g)
+    lod, dyd = to_nhwc(lo, cuda, c1), to_nhwc(dy, cuda, ops.pad_channels(cout))
+    got = ops.conv_wgrad_upcat(lod, None, dyd, cout)
+    assert got is not None
+    up = F.interpolate(rq(lo), scale_factor=2, mode="nearest")
+    ref = torch.nn.grad.conv2d_weight(up, (cout, c1, 3, 3), rq(dy), padding=1)
+    torch.cuda.synchronize()
+    assert (got.cpu() - ref).abs().max().item() <= 5e-4 * float(ref.abs().max())
