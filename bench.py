@@ -100,6 +100,8 @@ class KernelTimer:
             wco = 2 if (dy.shape[-1] > 32 or not (kh == 3 and stride == 1)) else 1
             wci = 2 if (x.shape[-1] > 32 and dt == "bf16") else 1
             sym = f"conv_wgrad_kernel<{dt},{kh}x{kw_},s{stride},w{wco}x{wci}>+reduce"
+            if dt == "bf16" and kh == 3 and stride == 1 and dy.shape[-1] <= 32 and x.shape[-1] <= 32:
+                sym = "conv3x3_thin_wgrad_kernel<bf16>+reduce"
             timer.records.append((sym, flops, s, e))
             return r
 
@@ -139,8 +141,41 @@ class KernelTimer:
                 timer.records.append((sym, 2.0 * B * H * W * w.rows_real * w.ch_real * 9, s, e))
             return y
 
+        # "normalise on load" forms (the BatchNorm + ReLU of the producing layer evaluated by the consumer): the same
+        # kernel families with the prologue template flag
+        orig_pro, orig_wpro = ops.conv2d_pro, ops.conv_wgrad_pro
+
+        def conv2d_pro(x, w, out_channels, *a, **kw):
+            if not timer.enabled:
+                return orig_pro(x, w, out_channels, *a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = orig_pro(x, w, out_channels, *a, **kw)
+            e.record()
+            B, Ho, Wo = y.shape[0], y.shape[1], y.shape[2]
+            if w.bco & 0x2000:
+                sym = f"conv3x3_thin_kernel<bf16,ci{w.ci_pitch},rows{w.rows}{',up' if kw.get('up') else ''},pro>"
+            else:
+                sym = f"conv3x3_ring16_kernel<bf16,co64,{'8x32' if Wo >= 32 else '16x16'}>"  # (+pro: same family)
+            timer.records.append((sym, 2.0 * B * Ho * Wo * w.rows_real * w.ch_real * 9, s, e))
+            return y
+
+        def conv_wgrad_pro(x, dy, co_real, ci_real, *a, **kw):
+            if not timer.enabled:
+                return orig_wpro(x, dy, co_real, ci_real, *a, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_wpro(x, dy, co_real, ci_real, *a, **kw)
+            e.record()
+            B, Ho, Wo = dy.shape[0], dy.shape[1], dy.shape[2]
+            thin = dy.shape[-1] <= 32 and x.shape[-1] <= 32
+            sym = ("conv3x3_thin_wgrad_kernel<bf16>+reduce" if thin else "conv_wgrad_kernel<bf16,3x3,s1,w2x2>+reduce")
+            timer.records.append((sym, 2.0 * B * Ho * Wo * co_real * ci_real * 9, s, e))
+            return r
+
         ops.conv2d, ops.conv_wgrad = conv2d, conv_wgrad
         ops.conv2d_dgrad_upcat, ops.conv2d_upcat = conv2d_dgrad_upcat, conv2d_upcat
+        ops.conv2d_pro, ops.conv_wgrad_pro = conv2d_pro, conv_wgrad_pro
 
         # ---- HBM-bound kernels, one kernel per bracket (algorithmic bytes = every tensor read or written once) ----
         orig_bn_apply, orig_sce = ops.bn_apply, ops.softmax_ce

@@ -34,6 +34,8 @@ struct ThinArgs {
   const float* bias;   // [Co] or null
   const void* res;     // same layout as out, or null
   float* stats;        // [tiles][2][Co] or null
+  const float* pro_sc; // PRO kernels: the convolution reads relu(in * pro_sc[c] + pro_sh[c]) (BatchNorm + ReLU of the
+  const float* pro_sh; //   producing layer, evaluated on the halo in LDS: no normalised tensor in memory)
   int B, H, W;         // output (= virtual input) size
   int Co;              // stored output channel pitch
   int relu;
@@ -80,7 +82,7 @@ struct ThinGeom {
   static_assert(SLOT % 16 == 0 && 2 * LDS_BYTES <= 160 * 1024, "two blocks per CU");
 };
 
-template <int CI, int MT, bool UP, bool POOL, bool STATS>
+template <int CI, int MT, bool UP, bool POOL, bool STATS, bool PRO = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_thin_kernel(ThinArgs a) {
   using G = ThinGeom<CI, MT>;
   using T = ffa_bf16;
@@ -153,6 +155,46 @@ __global__ void __launch_bounds__(256, 2) conv3x3_thin_kernel(ThinArgs a) {
     if (has_tail) thin_wait_and_meet<G::NHW>();
     else thin_wait_and_meet<G::NHW - 1>();
   };
+  // PRO ("normalise on load"): once this wave's own pieces of the tile have landed, thread t rewrites in LDS the
+  // pieces of LOGICAL 16-byte slot t % PPX of its pixels -- always the same 8 channels, whose scale / shift it keeps in
+  // registers for the whole launch, and always pieces this very wave's DMA wrote (a pixel's pieces are moved by PPX
+  // neighbouring lanes) -- except the zero padding (the padding of the normalised tensor is zero, not relu(shift)).
+  // Same fma / max / rounding as ffa_bn_apply: bit-identical to convolving the materialised tensor.
+  float psc[PRO ? 8 : 1], psh[PRO ? 8 : 1];
+  const int jj = tid % G::PPX;
+  if constexpr (PRO) {
+    ffa_load8<float>(a.pro_sc + jj * 8, psc);
+    ffa_load8<float>(a.pro_sh + jj * 8, psh);
+  }
+  auto fix_tile = [&](int t, int slot) {
+    if constexpr (PRO) {
+      int b, oy0, ox0;
+      tile_origin(t, b, oy0, ox0);
+      unsigned char* base = smem + slot * G::SLOT;
+#pragma unroll
+      for (int k = 0; k < G::NHW; ++k) {
+        const int hy = (hyx[k] >> 12) & 0xff, hx = (hyx[k] >> 4) & 0xff;
+        const int vy = oy0 - 1 + hy, vx = ox0 - 1 + hx;
+        if (hyx[k] >= 0 && vy >= 0 && vx >= 0 && vy < a.H && vx < a.W) {
+          const int phys = (CI == 32) ? (jj ^ (((hx >> 2) & 1) << 1)) : jj;
+          ffa_u32x4* ptr = reinterpret_cast<ffa_u32x4*>(base + (hy * G::IW + hx) * G::PIXB + phys * 16);
+          ffa_u32x4 v = *ptr;
+          float f[8];
+          f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+          f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+          f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+          f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = fmaxf(__builtin_fmaf(f[e], psc[e], psh[e]), 0.f);
+          v.x = ffa_pack_bf16x2(f[0], f[1]);
+          v.y = ffa_pack_bf16x2(f[2], f[3]);
+          v.z = ffa_pack_bf16x2(f[4], f[5]);
+          v.w = ffa_pack_bf16x2(f[6], f[7]);
+          *ptr = v;
+        }
+      }
+    }
+  };
 
   // ---- per-lane fragment read bases (slot base added per tile) ----
   // fragment nt of wave w: tile row w * (NT / 2) + (nt >> 1), columns 16 * (nt & 1) + col; tap (r, s) adds r rows, s pixels
@@ -185,7 +227,14 @@ __global__ void __launch_bounds__(256, 2) conv3x3_thin_kernel(ThinArgs a) {
   int slot = 0;
 
   for (; t < a.ntiles; t += gridDim.x) {
-    wait_tile();  // halo of tile t is in LDS for every wave; every wave is done with the slot of the tile before it
+    if constexpr (PRO) {
+      if (has_tail) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G::NHW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G::NHW - 1) : "memory");
+      fix_tile(t, slot);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      wait_tile();  // halo of tile t is in LDS for every wave; every wave is done with the slot of the tile before it
+    }
     {
       const int t2 = t + 2 * (int)gridDim.x;
       issue_halo(t2 < a.ntiles ? t2 : t, (slot + 2) % 3);
@@ -359,17 +408,25 @@ static int thin_launch(const ThinArgs& a, int up, int pool, hipStream_t stream) 
   int cap = pg ? atoi(pg) : 512;
   if (cap < 1) cap = 1;
   const int grid = a.ntiles < cap ? a.ntiles : cap;
-  const bool st = a.stats != nullptr;
-#define FFA_THIN_GO(UP_, POOL_, ST_)                                                                         \
-  hipLaunchKernelGGL((conv3x3_thin_kernel<CI, MT, UP_, POOL_, ST_>), dim3(grid), dim3(256), 0, stream, a); \
+  const bool st = a.stats != nullptr, pro = a.pro_sc != nullptr;
+#define FFA_THIN_GO(UP_, POOL_, ST_, PRO_)                                                                         \
+  hipLaunchKernelGGL((conv3x3_thin_kernel<CI, MT, UP_, POOL_, ST_, PRO_>), dim3(grid), dim3(256), 0, stream, a); \
   return ffa_check_launch("conv3x3_thin");
-  if (pool) { FFA_THIN_GO(false, true, false) }
-  if (up) {
-    if (st) { FFA_THIN_GO(true, false, true) }
-    FFA_THIN_GO(true, false, false)
+  if (pool) { FFA_THIN_GO(false, true, false, false) }
+  if (pro) {
+    if (up) {
+      if (st) { FFA_THIN_GO(true, false, true, true) }
+      FFA_THIN_GO(true, false, false, true)
+    }
+    if (st) { FFA_THIN_GO(false, false, true, true) }
+    FFA_THIN_GO(false, false, false, true)
   }
-  if (st) { FFA_THIN_GO(false, false, true) }
-  FFA_THIN_GO(false, false, false)
+  if (up) {
+    if (st) { FFA_THIN_GO(true, false, true, false) }
+    FFA_THIN_GO(true, false, false, false)
+  }
+  if (st) { FFA_THIN_GO(false, false, true, false) }
+  FFA_THIN_GO(false, false, false, false)
 #undef FFA_THIN_GO
 }
 
@@ -392,9 +449,23 @@ extern "C" long long ffa_thin_stat_rows(int B, int H, int W, int ci_pitch) {
 // in: [B][H][W][Ci] (up: [B][H/2][W/2][Ci]); out / residual: [B][H][W][Co] (pool: out [B][H/2][W/2][Co]).
 // co_rows = 16 or 32 (the packed operand's rows).  up: the input is nearest_x2 of `in`; pool: the output is 2x2
 // sum-pooled (no bias / residual / relu / statistics then).
+// pro_scale / pro_shift (both or neither, [Ci] f32): the convolution reads relu(in * scale[c] + shift[c]).
+extern "C" int ffa_thin_conv3x3_pro(const void* in, const void* w_thin, const float* bias, const void* residual,
+                                    void* out, float* stat_partials, const float* pro_scale, const float* pro_shift, int B,
+                                    int H, int W, int Ci, int Co, int co_rows, int relu, int up, int pool,
+                                    hipStream_t stream);
 extern "C" int ffa_thin_conv3x3(const void* in, const void* w_thin, const float* bias, const void* residual, void* out,
                                 float* stat_partials, int B, int H, int W, int Ci, int Co, int co_rows, int relu, int up,
                                 int pool, hipStream_t stream) {
+  return ffa_thin_conv3x3_pro(in, w_thin, bias, residual, out, stat_partials, nullptr, nullptr, B, H, W, Ci, Co, co_rows,
+                              relu, up, pool, stream);
+}
+extern "C" int ffa_thin_conv3x3_pro(const void* in, const void* w_thin, const float* bias, const void* residual,
+                                    void* out, float* stat_partials, const float* pro_scale, const float* pro_shift, int B,
+                                    int H, int W, int Ci, int Co, int co_rows, int relu, int up, int pool,
+                                    hipStream_t stream) {
+  FFA_REQUIRE((pro_scale == nullptr) == (pro_shift == nullptr) && !(pool && pro_scale),
+              "thin conv: prologue needs scale and shift (and is not part of the pooled form)");
   FFA_REQUIRE(in && w_thin && out, "thin conv: null pointer");
   FFA_REQUIRE(B > 0 && H > 0 && W > 0 && (Ci == 16 || Ci == 32) && (co_rows == 16 || co_rows == 32) && Co % 8 == 0,
               "thin conv: bad dims (Ci %d, Co %d, rows %d)", Ci, Co, co_rows);
@@ -404,6 +475,7 @@ extern "C" int ffa_thin_conv3x3(const void* in, const void* w_thin, const float*
   FFA_REQUIRE((long long)B * H * W * Ci * 2 < (1LL << 40), "thin conv: input too large");
   ThinArgs a;
   a.in = in; a.w = w_thin; a.out = out; a.bias = bias; a.res = residual; a.stats = stat_partials;
+  a.pro_sc = pro_scale; a.pro_sh = pro_shift;
   a.B = B; a.H = H; a.W = W; a.Co = Co; a.relu = relu;
   const int th = (Ci == 32) ? 8 : 16;
   a.tiles_x = ffa_cdiv(W, 32);

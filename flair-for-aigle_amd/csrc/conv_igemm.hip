@@ -1206,6 +1206,10 @@ extern "C" int ffa_thin_conv3x3(const void* in, const void* w_thin, const float*
                                 int pool, hipStream_t stream);
 extern "C" int ffa_thin_pack(const float* w_oihw, const float* scale, void* dst, int O, int I, int transpose, int co_rows,
                              int ci_pitch, hipStream_t stream);
+extern "C" int ffa_thin_conv3x3_pro(const void* in, const void* w_thin, const float* bias, const void* residual,
+                                    void* out, float* stat_partials, const float* pro_scale, const float* pro_shift, int B,
+                                    int H, int W, int Ci, int Co, int co_rows, int relu, int up, int pool,
+                                    hipStream_t stream);
 
 // Operand layout + block height for a layer: the value to hand to ffa_pack_conv_weight / ffa_conv2d as `bco`.
 // Bits 0..11 = rows per block (the padded row count is a multiple of it); FFA_BCO_RING set = the operand is packed
@@ -1311,6 +1315,27 @@ extern "C" int ffa_conv2d(int dtype, const void* in, const void* w_packed, const
                           int kh, int kw, int stride, int pad, int dil, int relu, hipStream_t stream) {
   return conv2d_impl(dtype, in, w_packed, bias, residual, out, nullptr, B, Hi, Wi, Ci, Ho, Wo, Co, co_rows, bco, kh, kw,
                      stride, pad, dil, relu, stream);
+}
+
+// 3x3 stride-1 pad-1 convolution of relu(in * pro_scale[c] + pro_shift[c]) -- the training-mode BatchNorm + ReLU of the
+// PRODUCING layer evaluated while this layer stages its input ("normalise on load": the normalised tensor is never
+// written; smp Conv2dReLU / torchvision BasicBlock chains conv -> BN -> ReLU -> conv).  bf16 operands in the ring16 or
+// thin layout (ffa_conv_plan); `in` is the PRE-normalisation tensor [B][H][W][Ci] -- or, up != 0, the low-resolution
+// map [B][H/2][W/2][Ci] of the skip-less nearest-x2 form (thin layout only).  Zero padding applies to the normalised
+// tensor.  stat_partials may be null.  Bit-identical to ffa_bn_apply followed by ffa_conv2d / ffa_conv2d_stats.
+// FFA_ERR_UNSUPPORTED for operands in the conv_igemm layout.
+extern "C" int ffa_conv2d_pro(int dtype, const void* in, const void* w_packed, const float* bias, const void* residual,
+                              void* out, float* stat_partials, const float* pro_scale, const float* pro_shift, int B,
+                              int H, int W, int Ci, int Co, int co_rows, int bco, int relu, int up, hipStream_t stream) {
+  FFA_REQUIRE(dtype == FFA_BF16 && in && w_packed && out && pro_scale && pro_shift, "conv_pro: bad arguments");
+  if (bco & FFA_BCO_THIN)
+    return ffa_thin_conv3x3_pro(in, w_packed, bias, residual, out, stat_partials, pro_scale, pro_shift, B, H, W, Ci, Co,
+                                co_rows, relu, up, 0, stream);
+  if ((bco & FFA_BCO_RING) && !up)
+    return ffa_ring_conv3x3(dtype, in, w_packed, bias, residual, out, stat_partials, pro_scale, pro_shift, B, H, W, Ci, Co,
+                            co_rows, relu, stream);
+  ffa_set_error("conv_pro: no prologue kernel for this operand layout (bco 0x%x, up %d)", bco, up);
+  return FFA_ERR_UNSUPPORTED;
 }
 
 // ffa_conv2d whose output is the gradient dy of y = relu(bn(x)) (a dgrad convolution feeding a BatchNorm

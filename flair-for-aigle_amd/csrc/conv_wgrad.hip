@@ -49,6 +49,10 @@ struct WgradArgs {
   const void* x2;
   int C1;
   int CoT, CiT;
+  // "normalise on load": the convolution input was relu(x * pro_sc[c] + pro_sh[c]) (BatchNorm + ReLU of the producing
+  // layer folded into the consumer): the staged x pieces are rewritten accordingly, padding stays zero
+  const float* pro_sc;
+  const float* pro_sh;
 };
 
 // WCO x WCI waves own distinct (co, ci) sub-tiles; WK further waves split the tile's k-steps (pixels) and
@@ -91,9 +95,10 @@ __device__ __forceinline__ ffa_s16x4 lds_read_tr16(const unsigned char* p) {
       (__attribute__((address_space(3))) ffa_s16x4*)(const_cast<unsigned char*>(p)));
 }
 
-template <typename T, int KH, int KW, int STRIDE, int RG, int WCO, int WCI, int WK, int TH, int TW>
+template <typename T, int KH, int KW, int STRIDE, int RG, int WCO, int WCI, int WK, int TH, int TW, bool PRO = false>
 __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1)) conv_wgrad_kernel(WgradArgs a) {
   constexpr int EB = ElemTraits<T>::kBytes;
+  static_assert(!PRO || (EB == 2 && KH == 3 && STRIDE == 1), "the prologue lives in the bf16 3x3 stride-1 path");
   using G = WgradGeom<KH, KW, STRIDE, RG, WCO, WCI, WK, TH, TW, EB>;
   __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
   unsigned char* sDy = smem;
@@ -241,11 +246,14 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
         v = *reinterpret_cast<const ffa_u32x4*>(dyt_ + (unsigned)drel[k]);                                     \
       dreg[k] = v;                                                                                             \
     }                                                                                                          \
+    ivalid = 0u;                                                                                               \
     _Pragma("unroll") for (int k = 0; k < G::NIP; ++k) {                                                       \
       ffa_u32x4 v = ffa_u32x4{0u, 0u, 0u, 0u};                                                                 \
       if (irel[k] != (int)0x80000000 && (unsigned)(iy0_ + (ipos[k] >> 8)) < (unsigned)a.Hi &&                  \
-          (unsigned)(ix0_ + (ipos[k] & 0xff)) < (unsigned)a.Wi)                                                \
+          (unsigned)(ix0_ + (ipos[k] & 0xff)) < (unsigned)a.Wi) {                                              \
         v = *reinterpret_cast<const ffa_u32x4*>(xt_ + (long long)irel[k]);                                     \
+        ivalid |= 1u << k;                                                                                     \
+      }                                                                                                        \
       ireg[k] = v;                                                                                             \
     }                                                                                                          \
   }
@@ -258,10 +266,37 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
     }                                                                                           \
     _Pragma("unroll") for (int k = 0; k < G::NIP; ++k) {                                        \
       const int i = tid + k * G::NTHR;                                                          \
-      if (G::IN_PIECES % G::NTHR == 0 || i < G::IN_PIECES)                                      \
-        *reinterpret_cast<ffa_u32x4*>(sIn + (size_t)i * 16) = ireg[k];                          \
+      if (G::IN_PIECES % G::NTHR == 0 || i < G::IN_PIECES) {                                    \
+        ffa_u32x4 v = ireg[k];                                                                  \
+        if constexpr (PRO) {                                                                    \
+          if (svalid & (1u << k)) v = pro_piece(v, i);                                          \
+        }                                                                                       \
+        *reinterpret_cast<ffa_u32x4*>(sIn + (size_t)i * 16) = v;                                \
+      }                                                                                         \
     }                                                                                           \
   }
+  // PRO: relu(x * sc + sh) on the 8 channels of piece i (channel = block origin + 32 * plane + 8 * part), same fma /
+  // max / rounding as ffa_bn_apply; only pieces that were really loaded (svalid): the zero padding stays zero
+  unsigned ivalid = 0u, svalid = 0u;
+  auto pro_piece = [&](ffa_u32x4 v, int i) {
+    const int part = i % G::PARTS;
+    const int plane = i / (G::PARTS * G::IH * G::IW);
+    const int c = xc0 + plane * 32 + part * 8;
+    float sc[8], sh[8], f[8];
+    ffa_load8<float>(a.pro_sc + c, sc);
+    ffa_load8<float>(a.pro_sh + c, sh);
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = fmaxf(__builtin_fmaf(f[e], sc[e], sh[e]), 0.f);
+    v.x = ffa_pack_bf16x2(f[0], f[1]);
+    v.y = ffa_pack_bf16x2(f[2], f[3]);
+    v.z = ffa_pack_bf16x2(f[4], f[5]);
+    v.w = ffa_pack_bf16x2(f[6], f[7]);
+    return v;
+  };
 
   int pt = split;
   if (pt < a.npt) FFA_WG_LOAD(pt)
@@ -269,6 +304,7 @@ __global__ void __launch_bounds__(64 * WCO * WCI * WK, (sizeof(T) == 2 ? 2 : 1))
   for (; pt < a.npt; pt += a.nsplit) {
     __syncthreads();  // previous tile's fragment reads are done
     FFA_WTRACE(2)
+    svalid = ivalid;  // validity of the pieces now in ireg[] (the next FFA_WG_LOAD rewrites ivalid)
     FFA_WG_STORE()    // piece i lives at byte i*16: [plane][pixel][32 ch] is linear in the piece index
     FFA_WTRACE(3)
     __syncthreads();
@@ -922,7 +958,7 @@ struct WgThinGeom {
   static_assert(2 * LDS_BYTES <= 160 * 1024, "two blocks per CU");
 };
 
-template <int CI, int CO, bool UP>
+template <int CI, int CO, bool UP, bool PRO = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_thin_wgrad_kernel(WgradArgs a) {
   using G = WgThinGeom<CI, CO>;
   constexpr int MT = G::MT, NT = G::NT;
@@ -992,10 +1028,53 @@ __global__ void __launch_bounds__(256, 2) conv3x3_thin_wgrad_kernel(WgradArgs a)
       }
     }
   };
+  // PRO: rewrite this thread's own x pieces of the landed tile as relu(x * sc + sh) (thin forward kernel's recipe:
+  // own pieces need only the wave's own vmcnt wait; the padding stays zero), then the block meets
+  auto fix_tile = [&](int t, int slot) {
+    if constexpr (PRO) {
+      int b, oy0, ox0;
+      tile_origin(t, b, oy0, ox0);
+      float sc[8], sh[8];
+      const int c0 = (tid % (G::XB / 16)) * 8;
+      ffa_load8<float>(a.pro_sc + c0, sc);
+      ffa_load8<float>(a.pro_sh + c0, sh);
+#pragma unroll
+      for (int k = 0; k < G::NHW; ++k) {
+        const int info = pinfo[k];
+        const int yy = (info >> 12) & 0xff, xx = (info >> 4) & 0xff;
+        const int vy = oy0 - 1 + yy, vx = ox0 - 1 + xx;
+        if (info >= 0 && !(info & (1 << 30)) && vy >= 0 && vx >= 0 && vy < a.Hi && vx < a.Wi) {
+          ffa_u32x4* ptr = reinterpret_cast<ffa_u32x4*>(smem + slot * G::SLOT + (tid + k * 256) * 16);
+          ffa_u32x4 v = *ptr;
+          float f[8];
+          f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+          f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+          f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+          f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = fmaxf(__builtin_fmaf(f[e], sc[e], sh[e]), 0.f);
+          v.x = ffa_pack_bf16x2(f[0], f[1]);
+          v.y = ffa_pack_bf16x2(f[2], f[3]);
+          v.z = ffa_pack_bf16x2(f[4], f[5]);
+          v.w = ffa_pack_bf16x2(f[6], f[7]);
+          *ptr = v;
+        }
+      }
+    }
+  };
   // wait until this wave's fill of the CURRENT tile has landed: with a three-slot ring one younger fill may stay in
   // flight, with two slots nothing younger exists at this point
-  auto wait_tile = [&]() {
-    if constexpr (G::NSLOT == 3) {
+  auto wait_tile = [&](int t, int slot) {
+    if constexpr (PRO) {
+      if constexpr (G::NSLOT == 3) {
+        if (has_tail) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G::NHW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(G::NHW - 1) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      fix_tile(t, slot);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else if constexpr (G::NSLOT == 3) {
       if (has_tail) wgthin_wait_and_meet<G::NHW>();
       else wgthin_wait_and_meet<G::NHW - 1>();
     } else {
@@ -1035,7 +1114,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_thin_wgrad_kernel(WgradArgs a)
     if constexpr (G::NSLOT == 3) issue_tile(t + stride < a.npt ? t + stride : t, 1);
     int slot = 0;
     for (; t < a.npt; t += stride) {
-      wait_tile();
+      wait_tile(t, slot);
       {
         const int tn = t + (G::NSLOT - 1) * stride;
         issue_tile(tn < a.npt ? tn : t, (slot + G::NSLOT - 1) % G::NSLOT);
@@ -1236,10 +1315,10 @@ extern "C" long long ffa_conv_wgrad_workspace_bytes(int dtype, int kh, int kw, i
   return need;
 }
 
-template <typename T, int KH, int KW, int STRIDE, int RG, int WCO, int WCI, int WK, int TH, int TW>
+template <typename T, int KH, int KW, int STRIDE, int RG, int WCO, int WCI, int WK, int TH, int TW, bool PRO = false>
 static void launch_wgrad_cfg(const WgradArgs& a, int nrg, hipStream_t stream) {
   dim3 grid(a.ncob * a.ncib * nrg, a.nsplit);
-  hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW, STRIDE, RG, WCO, WCI, WK, TH, TW>), grid,
+  hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW, STRIDE, RG, WCO, WCI, WK, TH, TW, PRO>), grid,
                      dim3(64 * WCO * WCI * WK), 0, stream, a);
 }
 
@@ -1249,11 +1328,13 @@ static int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int kh, int kw, 
   const bool wide = (p.tw == 32);
   if constexpr (!F32) {
     if (p.thin) {
-      const bool up = a.C1 > 0;
+      const bool up = a.C1 > 0, pro = a.pro_sc != nullptr;
 #define FFA_WGTHIN(CI_, CO_)                                                                                     \
   if (a.Ci == CI_ && a.Co == CO_) {                                                                              \
-    if (up) hipLaunchKernelGGL((conv3x3_thin_wgrad_kernel<CI_, CO_, true>), dim3(a.nsplit), dim3(256), 0, stream, a);  \
-    else hipLaunchKernelGGL((conv3x3_thin_wgrad_kernel<CI_, CO_, false>), dim3(a.nsplit), dim3(256), 0, stream, a);    \
+    if (up && pro) hipLaunchKernelGGL((conv3x3_thin_wgrad_kernel<CI_, CO_, true, true>), dim3(a.nsplit), dim3(256), 0, stream, a);   \
+    else if (up) hipLaunchKernelGGL((conv3x3_thin_wgrad_kernel<CI_, CO_, true, false>), dim3(a.nsplit), dim3(256), 0, stream, a);    \
+    else if (pro) hipLaunchKernelGGL((conv3x3_thin_wgrad_kernel<CI_, CO_, false, true>), dim3(a.nsplit), dim3(256), 0, stream, a);   \
+    else hipLaunchKernelGGL((conv3x3_thin_wgrad_kernel<CI_, CO_, false, false>), dim3(a.nsplit), dim3(256), 0, stream, a);           \
     return ffa_check_launch("conv3x3_thin_wgrad");                                                               \
   }
       FFA_WGTHIN(16, 16)
@@ -1282,6 +1363,15 @@ static int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int kh, int kw, 
       FFA_WG_S1(2, 1, 1, 4, 8)
       FFA_WG_S1(1, 1, 1, 4, 8)
     } else {
+      if (a.pro_sc) {  // normalise-on-load: the 64 x 64-channel block configuration only (the layers that use it)
+        if (!(p.wco == 2 && p.wci == 2 && p.wk == 2) || a.C1 > 0) {
+          ffa_set_error("conv_wgrad: no prologue for this channel configuration");
+          return FFA_ERR_UNSUPPORTED;
+        }
+        if (wide) launch_wgrad_cfg<T, 3, 3, 1, 3, 2, 2, 2, 8, 32, true>(a, 1, stream);
+        else launch_wgrad_cfg<T, 3, 3, 1, 3, 2, 2, 2, 16, 16, true>(a, 1, stream);
+        return ffa_check_launch("conv_wgrad");
+      }
       FFA_WG_S1(2, 2, 2, 8, 16)
       FFA_WG_S1(2, 1, 2, 4, 8)
       FFA_WG_S1(1, 2, 2, 4, 8)
@@ -1320,7 +1410,11 @@ static int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int kh, int kw, 
 // gradient is written for the first Co_real x Ci_real entries as OIHW f32 (accumulate != 0 adds to it).
 static int wgrad_impl(int dtype, const void* x, const void* x2, int C1, const void* dy, float* dw_oihw, int B, int Hi,
                       int Wi, int Ci, int Ho, int Wo, int Co, int Co_real, int Ci_real, int kh, int kw, int stride,
-                      int pad, int accumulate, void* workspace, long long workspace_bytes, hipStream_t stream) {
+                      int pad, int accumulate, void* workspace, long long workspace_bytes, hipStream_t stream,
+                      const float* pro_scale = nullptr, const float* pro_shift = nullptr) {
+  FFA_REQUIRE((pro_scale == nullptr) == (pro_shift == nullptr), "conv_wgrad: prologue needs scale and shift");
+  FFA_REQUIRE(!pro_scale || (dtype == FFA_BF16 && kh == 3 && kw == 3 && stride == 1 && pad == 1),
+              "conv_wgrad: the prologue is for bf16 3x3 stride-1 pad-1 layers");
   FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "conv_wgrad: bad dtype");
   FFA_REQUIRE(x && dy && dw_oihw && workspace, "conv_wgrad: null pointer");
   FFA_REQUIRE(Ci % 8 == 0 && Co % 8 == 0, "conv_wgrad: channel pitch must be a multiple of 8");
@@ -1347,6 +1441,7 @@ static int wgrad_impl(int dtype, const void* x, const void* x2, int C1, const vo
   WgradArgs a;
   a.x = x; a.dy = dy; a.slabs = static_cast<float*>(workspace);
   a.x2 = x2; a.C1 = C1;
+  a.pro_sc = pro_scale; a.pro_sh = pro_shift;
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci;
   a.Ho = Ho; a.Wo = Wo; a.Co = Co;
   a.pad = pad;
@@ -1393,6 +1488,20 @@ extern "C" int ffa_conv_wgrad(int dtype, const void* x, const void* dy, float* d
                               int accumulate, void* workspace, long long workspace_bytes, hipStream_t stream) {
   return wgrad_impl(dtype, x, nullptr, 0, dy, dw_oihw, B, Hi, Wi, Ci, Ho, Wo, Co, Co_real, Ci_real, kh, kw, stride, pad,
                     accumulate, workspace, workspace_bytes, stream);
+}
+
+// ffa_conv_wgrad / ffa_conv_wgrad_upcat (skip-less form: C2 = 0) for a layer whose input was relu(x * pro_scale[c] +
+// pro_shift[c]) -- the BatchNorm + ReLU of the producing layer folded into its consumers ("normalise on load"): x is the
+// PRE-normalisation tensor, the staged pieces are rewritten in the loader (same fma / max / rounding as ffa_bn_apply,
+// zero padding applied after the normalisation).  bf16, 3x3 stride 1 pad 1; up != 0: x is the low-resolution map of the
+// nearest-x2 form [B][Hi/2][Wi/2][Ci].  FFA_ERR_UNSUPPORTED for channel configurations without a prologue kernel.
+extern "C" int ffa_conv_wgrad_pro(int dtype, const void* x, const void* dy, float* dw_oihw, const float* pro_scale,
+                                  const float* pro_shift, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
+                                  int Co_real, int Ci_real, int up, int accumulate, void* workspace,
+                                  long long workspace_bytes, hipStream_t stream) {
+  FFA_REQUIRE(pro_scale && pro_shift, "conv_wgrad_pro: null prologue vectors");
+  return wgrad_impl(dtype, x, nullptr, up ? Ci : 0, dy, dw_oihw, B, Hi, Wi, Ci, Ho, Wo, Co, Co_real, Ci_real, 3, 3, 1, 1,
+                    accumulate, workspace, workspace_bytes, stream, pro_scale, pro_shift);
 }
 
 // Weight gradient of the 3x3 stride-1 pad-1 convolution whose input is the virtual cat(nearest_x2(lo), skip)

@@ -57,6 +57,8 @@ SIGNATURES = {
     "ffa_ring_conv3x3": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
     "ffa_ring_stat_rows": (_ll, [_i, _i, _i, _i]),
     "ffa_ring_pack": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "ffa_conv2d_pro": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 9 + [_p]),
+    "ffa_conv_wgrad_pro": (_i, [_i, _p, _p, _p, _p, _p] + [_i] * 11 + [_p, _ll, _p]),
     "ffa_thin_pack_bytes": (_ll, [_i, _i]),
     "ffa_thin_pack_desc_bytes": (_i, []),
     "ffa_thin_pack_desc_fill": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i]),

@@ -277,9 +277,17 @@ class _DecoderBlock(torch.autograd.Function):
         xa, sca, sha, ma, ra = ops.conv2d_upcat_bn_stats(lo, skip, ca.packed(lo.dtype, ring=False), ca.out_pitch, ga, ba,
                                                          na.running_mean, na.running_var, na.momentum, na.eps)
         na.note_batch()
-        ya = ops.bn_apply(xa, sca, sha, relu=True)
-        xb, scb, shb, mb, rb = ops.conv2d_bn_stats(ya, cb.packed(lo.dtype), cb.padding, cb.out_pitch, gb, bb,
-                                                   nb.running_mean, nb.running_var, nb.momentum, nb.eps)
+        pwb = cb.packed(lo.dtype)
+        # normalise-on-load: conv_b (and its weight gradient) read relu(xa * sca + sha) straight from xa
+        ctx.fold = ops.NORM_ON_LOAD and ops.pro_supported(pwb, lo.dtype) and not ops.FUSED_BN_BWD
+        if ctx.fold:
+            ya = None
+            xb, scb, shb, mb, rb = ops.conv2d_pro_bn_stats(xa, pwb, cb.out_pitch, sca, sha, gb, bb, nb.running_mean,
+                                                           nb.running_var, nb.momentum, nb.eps)
+        else:
+            ya = ops.bn_apply(xa, sca, sha, relu=True)
+            xb, scb, shb, mb, rb = ops.conv2d_bn_stats(ya, pwb, cb.padding, cb.out_pitch, gb, bb,
+                                                       nb.running_mean, nb.running_var, nb.momentum, nb.eps)
         nb.note_batch()
         y = ops.bn_apply(xb, scb, shb, relu=True)
         ctx.blk = blk
@@ -292,14 +300,18 @@ class _DecoderBlock(torch.autograd.Function):
         blk = ctx.blk
         ca, cb = blk.conv1[0], blk.conv2[0]
         db_, _, dgb, dbb = ops.bn_bwd(xb, _as_nhwc_grad(dy), None, gb, bb, mb, rb, True, False)
-        dwb = (ops.conv_wgrad(ya, db_, cb.out_channels, cb.in_channels, 3, 3, 1, 1, out=_dw_out(cb))
-               if ctx.needs_input_grad[5] else None)
+        dwb = None
+        if ctx.needs_input_grad[5]:
+            if ctx.fold:
+                dwb = ops.conv_wgrad_pro(xa, db_, cb.out_channels, cb.in_channels, sca, sha, out=_dw_out(cb))
+            else:
+                dwb = ops.conv_wgrad(ya, db_, cb.out_channels, cb.in_channels, 3, 3, 1, 1, out=_dw_out(cb))
         pbt = cb.packed(db_.dtype, transpose=True, ring=not ops.FUSED_BN_BWD, thin=not ops.FUSED_BN_BWD)
         if ops.FUSED_BN_BWD:
-            dya, part, rows = ops.conv2d_bnbwd(db_, pbt, 1, ya.shape[-1], xa, sca, sha)
+            dya, part, rows = ops.conv2d_bnbwd(db_, pbt, 1, xa.shape[-1], xa, sca, sha)
             da, dga, dba = ops.bn_bwd_partials(xa, dya, part, rows, ga, ba, ma, ra)
         else:
-            dya = ops.conv2d(db_, pbt, 1, ya.shape[-1])
+            dya = ops.conv2d(db_, pbt, 1, xa.shape[-1])
             da, _, dga, dba = ops.bn_bwd(xa, dya, None, ga, ba, ma, ra, True, False)
         dlo = dskip = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
@@ -332,7 +344,10 @@ class _BasicBlock(torch.autograd.Function):
         x1, sc1, sh1, m1, r1 = ops.conv2d_bn_stats(x, c1.packed(x.dtype), c1.padding, c1.out_pitch, g1, b1,
                                                    n1.running_mean, n1.running_var, n1.momentum, n1.eps)
         n1.note_batch()
-        y1 = ops.bn_apply(x1, sc1, sh1, relu=True)
+        pw2 = c2.packed(x.dtype)
+        # normalise-on-load: conv2 (and its weight gradient) read relu(x1 * sc1 + sh1) straight from x1
+        ctx.fold = ops.NORM_ON_LOAD and ops.pro_supported(pw2, x.dtype) and not ops.FUSED_BN_BWD and c2.padding == 1
+        y1 = None if ctx.fold else ops.bn_apply(x1, sc1, sh1, relu=True)
         if down:
             cd, nd = blk.downsample[0], blk.downsample[1]
             xd, scd, shd, md, rd = ops.conv2d_bn_stats(x, cd.packed(x.dtype), cd.padding, cd.out_pitch, gd, bd,
@@ -342,8 +357,12 @@ class _BasicBlock(torch.autograd.Function):
         else:
             xd = md = rd = None
             idt = x
-        x2, sc2, sh2, m2, r2 = ops.conv2d_bn_stats(y1, c2.packed(x.dtype), c2.padding, c2.out_pitch, g2, b2,
-                                                   n2.running_mean, n2.running_var, n2.momentum, n2.eps)
+        if ctx.fold:
+            x2, sc2, sh2, m2, r2 = ops.conv2d_pro_bn_stats(x1, pw2, c2.out_pitch, sc1, sh1, g2, b2, n2.running_mean,
+                                                           n2.running_var, n2.momentum, n2.eps)
+        else:
+            x2, sc2, sh2, m2, r2 = ops.conv2d_bn_stats(y1, pw2, c2.padding, c2.out_pitch, g2, b2,
+                                                       n2.running_mean, n2.running_var, n2.momentum, n2.eps)
         n2.note_batch()
         y = ops.bn_apply(x2, sc2, sh2, residual=idt, relu=True)
         ctx.blk = blk
@@ -371,14 +390,17 @@ class _BasicBlock(torch.autograd.Function):
                                   conv.stride, conv.padding, out=_dw_out(conv))
 
         d2, dres, dg2, db2 = ops.bn_bwd(x2, dy, y, g2, b2, m2, r2, True, True)
-        dw2 = wgrad(c2, y1, d2) if ctx.needs_input_grad[4] else None
+        dw2 = None
+        if ctx.needs_input_grad[4]:
+            dw2 = (ops.conv_wgrad_pro(x1, d2, c2.out_channels, c2.in_channels, sc1, sh1, out=_dw_out(c2)) if ctx.fold
+                   else wgrad(c2, y1, d2))
         if ops.FUSED_BN_BWD:
             # bn1's backward reductions come out of conv2's dgrad epilogue (one pass over x1 and dy1 fewer)
             dy1, part, rows = ops.conv2d_bnbwd(d2, c2.packed(d2.dtype, transpose=True, ring=False, thin=False), c2.kernel_size - 1 - c2.padding,
-                                               y1.shape[-1], x1, sc1, sh1)
+                                               x1.shape[-1], x1, sc1, sh1)
             d1, dg1, db1 = ops.bn_bwd_partials(x1, dy1, part, rows, g1, b1, m1, r1)
         else:
-            dy1 = dgrad(c2, d2, y1)
+            dy1 = dgrad(c2, d2, x1)
             d1, _, dg1, db1 = ops.bn_bwd(x1, dy1, None, g1, b1, m1, r1, True, False)
         dw1 = wgrad(c1, x, d1) if ctx.needs_input_grad[1] else None
         dwd = dgd = dbd = None

@@ -387,6 +387,79 @@ def conv2d_bn_stats(x: torch.Tensor, w: PackedWeight, pad: int, out_channels: in
                                 momentum, eps)
 
 
+# "Normalise on load" (round 3): the BatchNorm + ReLU between two convolutions is evaluated by the CONSUMERS (the next
+# conv's forward and weight gradient) while they stage their input, so the normalised tensor is never written.
+# Implemented for every consumer kernel family of the U-Net (ring16, thin forward, thin / general weight gradient),
+# bit-identical to the materialised form (tests/test_thin_conv_gpu.py, tests/test_ring_conv_gpu.py) -- and measured
+# SLOWER in the step (same box, rocprofv3 kernel time per step 13.99 ms without, 14.36 ms with): the 21 saved
+# bn_apply passes are worth 0.34 ms, the prologue costs conv3x3_ring16_kernel +10.7 us per launch (52.5 vs 41.8: an LDS
+# read-modify-write of every halo piece and an earlier vmcnt drain, in a kernel that has no idle issue slots),
+# conv_wgrad_kernel +12 us (68.7 vs 56.6) and the thin kernels +19 ... +51 us.  Off by default;
+# FFA_NORM_ON_LOAD=1 turns it on.
+NORM_ON_LOAD = os.environ.get("FFA_NORM_ON_LOAD", "0") == "1"
+
+
+def pro_supported(w: "PackedWeight", dtype: torch.dtype, up: bool = False) -> bool:
+    """True when conv2d_pro / conv_wgrad_pro exist for this operand: bf16, ring16 layout (>= 64 channels) or thin layout"""
+    if dtype != torch.bfloat16 or w.kh != 3 or w.stride != 1:
+        return False
+    if w.bco & _l.BCO_THIN:
+        return True
+    return bool(w.bco & _l.BCO_RING) and not up and w.rows_real >= 64 and w.ch_real >= 64 and w.ci_pitch % 64 == 0
+
+
+def conv2d_pro(x: torch.Tensor, w: PackedWeight, out_channels: int, pro_scale: torch.Tensor, pro_shift: torch.Tensor,
+               bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, relu: bool = False,
+               stats: Optional[torch.Tensor] = None, up: bool = False) -> torch.Tensor:
+    """3x3 pad-1 conv of relu(x * pro_scale + pro_shift) without the normalised tensor (ffa_conv2d_pro); up: x is the
+    low-resolution map of the skip-less nearest-x2 form (thin layout)."""
+    lib = _l.load()
+    _chk_nhwc(x, "conv input")
+    B, Hs, Ws, Ci = x.shape
+    H, W = (2 * Hs, 2 * Ws) if up else (Hs, Ws)
+    if Ci != w.ci_pitch or pro_scale.numel() < Ci or pro_shift.numel() < Ci:
+        raise ValueError("conv2d_pro: operand / prologue vector mismatch")
+    out = torch.empty((B, H, W, out_channels), dtype=x.dtype, device=x.device)
+    if stats is not None and (stats.dtype != torch.float32 or stats.numel() < conv_stat_rows(B, H, W, w) * 2 * out_channels):
+        raise ValueError("conv2d_pro: statistics buffer too small or not f32")
+    _l.check(lib.ffa_conv2d_pro(_dt(x), x.data_ptr(), w.data.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(),
+                                _ptr(stats), pro_scale.data_ptr(), pro_shift.data_ptr(), B, H, W, Ci, out_channels, w.rows,
+                                w.bco, 1 if relu else 0, 1 if up else 0, _stream()), "conv2d_pro")
+    return out
+
+
+def conv2d_pro_bn_stats(x: torch.Tensor, w: PackedWeight, out_channels: int, pro_scale, pro_shift, gamma, beta,
+                        running_mean, running_var, momentum: float, eps: float, up: bool = False):
+    """conv2d_pro + batch statistics of its output -> (y0, scale, shift, mean, rstd)"""
+    B, Hs, Ws, _ = x.shape
+    H, W = (2 * Hs, 2 * Ws) if up else (Hs, Ws)
+    rows = conv_stat_rows(B, H, W, w)
+    part = workspace(rows * 2 * out_channels * 4, x.device, "bnpart").view(torch.float32)
+    y0 = conv2d_pro(x, w, out_channels, pro_scale, pro_shift, stats=part, up=up)
+    return (y0,) + _bn_finalize(part, rows, B * H * W, out_channels, gamma, beta, running_mean, running_var, momentum, eps)
+
+
+def conv_wgrad_pro(x: torch.Tensor, dy: torch.Tensor, co_real: int, ci_real: int, pro_scale: torch.Tensor,
+                   pro_shift: torch.Tensor, up: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dW of the 3x3 pad-1 conv whose input was relu(x * pro_scale + pro_shift) (ffa_conv_wgrad_pro)"""
+    lib = _l.load()
+    _chk_nhwc(x, "wgrad input")
+    _chk_nhwc(dy, "wgrad dy")
+    B, Hs, Ws, Ci = x.shape
+    _, Ho, Wo, Co = dy.shape
+    did = _dt(x)
+    need = lib.ffa_conv_wgrad_workspace_bytes(did, 3, 3, 1, Co, Ci, B, Ho, Wo)
+    if need < 0:
+        raise _l.FlairHipError("no wgrad kernel")
+    ws = workspace(need, x.device, "wgrad")
+    if out is None:
+        out = torch.empty((co_real, ci_real, 3, 3), dtype=torch.float32, device=x.device)
+    _l.check(lib.ffa_conv_wgrad_pro(did, x.data_ptr(), dy.data_ptr(), out.data_ptr(), pro_scale.data_ptr(),
+                                    pro_shift.data_ptr(), B, Ho, Wo, Ci, Ho, Wo, Co, co_real, ci_real, 1 if up else 0, 0,
+                                    ws.data_ptr(), ws.numel(), _stream()), "conv_wgrad_pro")
+    return out
+
+
 def upcat_supported(c1: int, c2: int, dtype: torch.dtype) -> bool:
     """Channel splits the two-source kernels take (ffa_conv2d_upcat: C1 covers whole halo channel groups;
     ffa_conv_wgrad_upcat: C1 is a multiple of a block's input channels)."""

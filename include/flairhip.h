@@ -136,6 +136,21 @@ int ffa_conv_wgrad_upcat(int dtype, const void* lo, const void* skip, const void
                          int Wl, int C1, int C2, int Co, int Co_real, int accumulate, void* workspace,
                          long long workspace_bytes, ffa_stream_t stream);
 
+/* "Normalise on load" (round 3): a convolution / weight gradient whose input is relu(x * pro_scale[c] + pro_shift[c]),
+ * the training-mode BatchNorm + ReLU of the PRODUCING layer (smp Conv2dReLU -> Conv2dReLU, torchvision BasicBlock conv1 ->
+ * bn1 -> relu -> conv2: flair_hub/models/monotemp_model.py:68-92), evaluated while the consumer stages x -- the
+ * normalised tensor is never written (replaces ffa_bn_apply + ffa_conv2d[_stats] / ffa_conv_wgrad; bit-identical to that
+ * sequence, zero padding applied after the normalisation).  bf16, 3x3 stride 1 pad 1; operands in the ring16 / thin
+ * layouts of ffa_conv_plan.  up != 0: x is the low-resolution map of the skip-less nearest-x2 form.
+ * FFA_ERR_UNSUPPORTED where no prologue kernel exists (the caller then materialises the tensor). */
+int ffa_conv2d_pro(int dtype, const void* in, const void* w_packed, const float* bias, const void* residual, void* out,
+                   float* stat_partials, const float* pro_scale, const float* pro_shift, int B, int H, int W, int Ci,
+                   int Co, int co_rows, int bco, int relu, int up, ffa_stream_t stream);
+int ffa_conv_wgrad_pro(int dtype, const void* x, const void* dy, float* dw_oihw, const float* pro_scale,
+                       const float* pro_shift, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int Co_real,
+                       int Ci_real, int up, int accumulate, void* workspace, long long workspace_bytes,
+                       ffa_stream_t stream);
+
 /* ---- U-TAE Sentinel time-series branch (flair_hub/models/multitemp_model.py) ------------------
  * Small NHWC kernels around ffa_conv2d for the temporally shared encoder, the L-TAE and the attention-weighted skip
  * aggregation; evaluation-mode forward. */

@@ -173,3 +173,45 @@ def test_thin_wgrad_of_the_upsampled_input(cuda):
     ref = torch.nn.grad.conv2d_weight(up, (cout, c1, 3, 3), rq(dy), padding=1)
     torch.cuda.synchronize()
     assert (got.cpu() - ref).abs().max().item() <= 5e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,H,W,up", [(16, 16, 32, 64, False), (32, 32, 24, 40, False), (16, 19, 40, 40, False),
+                                              (32, 16, 20, 24, True), (64, 64, 24, 40, False), (128, 64, 16, 32, False)])
+def test_normalise_on_load_equals_the_materialised_tensor(cuda, monkeypatch, cin, cout, H, W, up):
+    """ffa_conv2d_pro / ffa_conv_wgrad_pro: conv and weight gradient of relu(x * sc + sh) with the normalisation done on
+    the staged input (thin kernels: LDS fix-up of the DMA'd halo; ring16: the same; conv_wgrad_kernel: at the LDS store)
+    == the same kernels run on the tensor ffa_bn_apply writes, bit for bit (zero padding applied after the
+    normalisation: positive shifts would show otherwise)."""
+    from flairhip import ops
+    monkeypatch.setenv("FFA_THIN_GRID", "6")
+    monkeypatch.setenv("FFA_RING_GRID", "8")
+    g = torch.Generator().manual_seed(cin + cout + H)
+    B = 2
+    cip = ops.pad_channels(cin)
+    cop = 32 if cout == 19 else ops.pad_channels(cout)
+    Hs, Ws = (H // 2, W // 2) if up else (H, W)
+    x = to_nhwc(torch.randn(B, cin, Hs, Ws, generator=g), cuda, cip)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(cuda)
+    sc = torch.zeros(cip, device=cuda)
+    sh = torch.zeros(cip, device=cuda)
+    sc[:cin] = (torch.rand(cin, generator=g) + 0.5).to(cuda)
+    sh[:cin] = (torch.randn(cin, generator=g) * 0.5 + 0.3).to(cuda)
+    dy = to_nhwc(torch.randn(B, cout, H, W, generator=g), cuda, cop)
+    pw = ops.pack_conv_weight(w, BF, 1, cip)
+    assert ops.pro_supported(pw, BF, up)
+    xn = ops.bn_apply(x, sc, sh, relu=True)
+    rows = ops.conv_stat_rows(B, H, W, pw)
+    st_a = torch.zeros(rows * 2 * cop, device=cuda)
+    st_b = torch.zeros(rows * 2 * cop, device=cuda)
+    if up:
+        ref = ops.conv2d_upcat(xn, None, pw, cop, stats=st_a)
+        ref_w = ops.conv_wgrad_upcat(xn, None, dy, cout)
+    else:
+        ref = ops.conv2d(xn, pw, 1, cop, stats=st_a)
+        ref_w = ops.conv_wgrad(xn, dy, cout, cin, 3, 3, 1, 1)
+    got = ops.conv2d_pro(x, pw, cop, sc, sh, stats=st_b, up=up)
+    got_w = ops.conv_wgrad_pro(x, dy, cout, cin, sc, sh, up=up)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    assert torch.equal(st_a, st_b)
+    assert torch.equal(got_w, ref_w)
