@@ -1196,6 +1196,233 @@ __global__ void __launch_bounds__(256, 2) conv3x3_thin_wgrad_kernel(WgradArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// 64 x 64-channel blocks of the bulk of the network (bf16, 3x3 stride 1 pad 1, Co and Ci multiples of 64, maps at least 32
+// wide; round 3): conv3x3_thin_wgrad_kernel's recipe -- v_mfma_f32_16x16x32_bf16 on transposed LDS reads, operands by
+// LDS-DMA into a second slot while the first is multiplied, no LDS store phase, no staging registers -- at the channel
+// decomposition of conv_wgrad_kernel<2, 2, 2>: eight waves = two k groups (rows 0-3 / 4-7 of the 8 x 32 tile) x (2 co x
+// 2 ci) sub-tiles of 32 x 32 channels x 9 taps (144 accumulator registers), one block per CU, the k groups merged
+// through LDS, one f32 slab per block, wgrad_reduce* unchanged.  conv_wgrad_kernel spent ~20 % of a tile storing its
+// register-staged pieces to LDS with every wave of the CU off the matrix pipe.
+// LDS images: [pixel][64 channels = 128 B]; the 16-byte slot index of a pixel is XORed with 2 * phi(column), phi = bit 1 |
+// bit 3 << 1 of the pixel's column in its image: conflict-free ds_read_b64_tr_b16 for every tap shift (enumerated),
+// applied on the DMA source address.
+
+struct Wg64Geom {
+  static constexpr int TH = 8, TW = 32, IH = 10, IW = 34;
+  static constexpr int XP = IH * IW * 8, YP = TH * TW * 8;  // 16-byte pieces
+  static constexpr int PIECES = XP + YP;
+  static constexpr int NHW = (PIECES + 511) / 512;
+  static constexpr int X_BYTES = XP * 16;
+  static constexpr int SLOT = PIECES * 16;
+  static constexpr int ACC_BYTES = 144 * 64 * 4;  // one wave
+  static constexpr int LDS_BYTES = (2 * SLOT > 4 * ACC_BYTES) ? 2 * SLOT : 4 * ACC_BYTES;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+__device__ __forceinline__ int wg64_phi(int px) { return ((px >> 1) & 1) | (((px >> 3) & 1) << 1); }
+
+__global__ void __launch_bounds__(512) conv3x3_wgrad64_kernel(WgradArgs a) {
+  using G = Wg64Geom;
+  __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kgp = wave >> 2;             // k group: tile rows 4 * kgp .. 4 * kgp + 3
+  const int wco = (wave >> 1) & 1, wci = wave & 1;
+  const int li = lane & 15, kg = lane >> 4;
+  const int cib = blockIdx.x % a.ncib, cob = blockIdx.x / a.ncib;
+  const int co0 = cob * 64, ci0 = cib * 64;
+  const int split = blockIdx.y;
+
+  const size_t xpb = (size_t)a.Ci * 2, ypb = (size_t)a.Co * 2;  // global bytes per pixel
+  // per 16-byte piece of a slot (x halo, then the dy tile), fixed for the launch: offset of its source from the tile's
+  // origin pixel in 16-byte units << 12 | dy piece << 11 | no piece << 10 | row << 6 | column; the swizzle is in the offset
+  int pinfo[G::NHW];
+#pragma unroll
+  for (int k = 0; k < G::NHW; ++k) {
+    const int p = tid + k * 512;
+    if (p < G::XP) {
+      const int q = p >> 3, yy = q / G::IW, xx = q % G::IW, sl = (p & 7) ^ (2 * wg64_phi(xx));
+      pinfo[k] = ((((yy * a.Wi + xx) * (int)xpb) >> 4) + sl) << 12 | (yy << 6) | xx;
+    } else if (p < G::PIECES) {
+      const int q = (p - G::XP) >> 3, yy = q / G::TW, xx = q % G::TW, sl = (p & 7) ^ (2 * wg64_phi(xx));
+      pinfo[k] = ((((yy * a.Wo + xx) * (int)ypb) >> 4) + sl) << 12 | (1 << 11) | (yy << 6) | xx;
+    } else {
+      pinfo[k] = 1 << 10;
+    }
+  }
+  const unsigned char* x_b = static_cast<const unsigned char*>(a.x) + ci0 * 2;
+  const unsigned char* dy_b = static_cast<const unsigned char*>(a.dy) + co0 * 2;
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(ffa_wgthin_zero16);
+  const bool has_tail = (G::PIECES % 512 == 0) || (wave * 64 + (G::NHW - 1) * 512 < G::PIECES);
+
+  auto tile_origin = [&](int t, int& b, int& oy0, int& ox0) {
+    const int tx = t % a.tiles_x;
+    const int t2 = t / a.tiles_x;
+    oy0 = (t2 % a.tiles_y) * G::TH;
+    b = t2 / a.tiles_y;
+    ox0 = tx * G::TW;
+  };
+  // a piece's source = tile origin (block-uniform, 64-bit) + a per-piece 32-bit offset fixed for the launch; validity is
+  // two unsigned compares: ~10 VALU per piece, no branches (the straightforward form cost ~40 instructions a piece
+  // = a quarter of a tile's matrix time with every wave of the CU off the pipe)
+  auto issue_tile = [&](int t, int slot) {
+    int b, oy0, ox0;
+    tile_origin(t, b, oy0, ox0);
+    const unsigned char* xt = x_b + ((long long)(b * a.Hi + oy0 - 1) * a.Wi + ox0 - 1) * (long long)xpb;
+    const unsigned char* yt = dy_b + ((long long)(b * a.Ho + oy0) * a.Wo + ox0) * (long long)ypb;
+#pragma unroll
+    for (int k = 0; k < G::NHW; ++k) {
+      const int info = pinfo[k];
+      const int yy = (info >> 6) & 15, xx = info & 63;
+      // pieces 0 .. XP-1 are x: k < XP / 512 all x, k > XP / 512 all dy, one mixed k
+      const bool mixed = (k == G::XP / 512) && (G::XP % 512 != 0);
+      const bool is_dy = mixed ? (info & (1 << 11)) != 0 : (k * 512 >= G::XP);
+      const int oy = yy + (is_dy ? oy0 : oy0 - 1), ox = xx + (is_dy ? ox0 : ox0 - 1);
+      const bool valid = (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo;
+      const unsigned char* src = valid ? (is_dy ? yt : xt) + (size_t)(((unsigned)info >> 12) << 4) : zero;
+      const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(
+          smem + slot * G::SLOT + (wave * 64 + k * 512) * 16);
+      if (k + 1 < G::NHW || G::PIECES % 512 == 0) {
+        wgthin_dma16(src, dst);
+      } else if (has_tail) {
+        if (!(info & (1 << 10))) wgthin_dma16(src, dst);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // one piece's address registers at a time (144 accumulators are live)
+    }
+  };
+
+  ffa_f32x4 acc[2][2][9];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) acc[mt][nt][tp] = ffa_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing: lane (li, kg) supplies pixel k = 8 * kg + (li >> 2) (+ 4 for the second read) of a 32-pixel
+  // k-step, 8-byte segment li & 3 of a 16-channel tile; physical 16-byte slot = (2 * tile + (li >> 1 & 1)) ^ 2 * phi(pixel)
+  const int kpx = 8 * kg + (li >> 2);
+  const int seg = (li & 1) * 8, hbit = (li >> 1) & 1;
+  // dy: pixel index in its image = row * 32 + kpx (+ 4): bits 1 and 3 do not depend on the row or the + 4
+  const int yphi = wg64_phi(kpx);
+  int aoff[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+    aoff[mt] = G::X_BYTES + ((4 * kgp) * G::TW + kpx) * 128 + (((2 * (wco * 2 + mt) + hbit) ^ (2 * yphi)) * 16) + seg;
+
+  // x: the swizzle is a function of the halo COLUMN (a halo row is 34 * 128 B = 17 times all 64 banks: rows do not move
+  // banks), so a tap's row is an immediate offset and the lane part is one of 3 (tap column) x 2 (tile) x 2 (read) values
+  int boff[3][2][2];
+#pragma unroll
+  for (int sx = 0; sx < 3; ++sx)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int hx = kpx + sx + 4 * h;
+        boff[sx][nt][h] = hx * 128 + (((2 * (wci * 2 + nt) + hbit) ^ (2 * wg64_phi(hx))) * 16) + seg;
+      }
+  auto tr2 = [&](const unsigned char* p0, const unsigned char* p1) {
+    const ffa_s16x4 v0 = lds_read_tr16(p0);
+    const ffa_s16x4 v1 = lds_read_tr16(p1);
+    ffa_u32x4 f;
+    f.x = __builtin_bit_cast(ffa_u32x2, v0).x;
+    f.y = __builtin_bit_cast(ffa_u32x2, v0).y;
+    f.z = __builtin_bit_cast(ffa_u32x2, v1).x;
+    f.w = __builtin_bit_cast(ffa_u32x2, v1).y;
+    return f;
+  };
+
+  const int ntl = (a.npt - split + a.nsplit - 1) / a.nsplit;  // tiles split, split + nsplit, ...
+  if (ntl > 0) {
+    issue_tile(split, 0);
+    int slot = 0;
+    for (int it = 0; it < ntl; ++it) {
+      wgthin_wait_and_meet<0>();  // this tile's fill has landed (nothing younger is in flight); the other slot is free
+      // the two waves of a SIMD are the two k groups of one (co, ci) sub-tile: group 0 issues the next tile's fill now,
+      // group 1 after half of its products, so that one of them is always feeding the matrix pipe
+      const bool more = it + 1 < ntl;
+      if (more) issue_tile(split + (it + 1) * a.nsplit, slot ^ 1);
+      const unsigned char* sS = smem + slot * G::SLOT;
+      // the k group's four rows = four k-steps of 32 pixels.  Tap (r, s) of row rr reads halo row rr + r at column shift s:
+      // each of the 6 x 3 (halo row, shift) fragments is read ONCE and multiplied with the dy fragments of the up to
+      // three rows it serves (half the LDS reads of a per-tap walk, which were the kernel's bound: 160 reads of 512 B per
+      // wave and tile = 1.1 x the matrix pipe's time)
+      ffa_u32x4 af[4][2];  // row hr is read when halo row hr starts and dies after halo row hr + 2: two or three rows live
+      const unsigned char* sRow = sS + (4 * kgp) * (G::IW * 128);
+#pragma unroll
+      for (int hr = 0; hr < 6; ++hr) {
+        if (hr < 4) {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            af[hr][mt] = tr2(sS + aoff[mt] + hr * G::TW * 128, sS + aoff[mt] + hr * G::TW * 128 + 4 * 128);
+        }
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const ffa_u32x4 bf = tr2(sRow + hr * (G::IW * 128) + boff[sx][nt][0], sRow + hr * (G::IW * 128) + boff[sx][nt][1]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+              const int rr = hr - r;
+              if (rr < 0 || rr > 3) continue;
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt)
+                acc[mt][nt][r * 3 + sx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(ffa_bf16x8, af[rr][mt]), __builtin_bit_cast(ffa_bf16x8, bf), acc[mt][nt][r * 3 + sx], 0, 0,
+                    0);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      slot ^= 1;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // ---- k group 1 -> LDS, k group 0 adds and writes the block's slab ----
+  float* red = reinterpret_cast<float*>(smem) + (size_t)(wave & 3) * 144 * 64 + lane;
+  if (kgp == 1) {
+    int o = 0;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) red[(o++) * 64] = acc[mt][nt][tp][i];
+  }
+  __syncthreads();
+  if (kgp == 1) return;
+  {
+    int o = 0;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[mt][nt][tp][i] += red[(o++) * 64];
+  }
+  float* slab = a.slabs + (size_t)split * a.CoT * 9 * a.CiT;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int co = co0 + wco * 32 + mt * 16 + 4 * kg + i, ci = ci0 + wci * 32 + nt * 16 + li;
+          slab[((size_t)co * 9 + tp) * a.CiT + ci] = acc[mt][nt][tp][i];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 
 struct WgradPlan {
   int wco, wci, wk, th, tw, rg, nsplit, ncob, ncib, CoT, CiT, npt, tiles_x, tiles_y, ring, nslab, stem, thin;
@@ -1371,6 +1598,16 @@ static int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int kh, int kw, 
         if (wide) launch_wgrad_cfg<T, 3, 3, 1, 3, 2, 2, 2, 8, 32, true>(a, 1, stream);
         else launch_wgrad_cfg<T, 3, 3, 1, 3, 2, 2, 2, 16, 16, true>(a, 1, stream);
         return ffa_check_launch("conv_wgrad");
+      }
+      {
+        // conv3x3_wgrad64_kernel: whole 64-channel blocks, wide maps, single source (FFA_WGRAD64=0: conv_wgrad_kernel)
+        const char* e64 = getenv("FFA_WGRAD64");
+        if (!(e64 && e64[0] == '0') && p.wco == 2 && p.wci == 2 && p.wk == 2 && wide && p.th == 8 && a.C1 == 0 &&
+            a.pad == 1 && a.Co % 64 == 0 && a.Ci % 64 == 0 &&
+            (10LL * a.Wi + 34) * 2 * (a.Ci > a.Co ? a.Ci : a.Co) < (1LL << 24)) {
+          hipLaunchKernelGGL(conv3x3_wgrad64_kernel, dim3(a.ncob * a.ncib, a.nsplit), dim3(512), 0, stream, a);
+          return ffa_check_launch("conv3x3_wgrad64");
+        }
       }
       FFA_WG_S1(2, 2, 2, 8, 16)
       FFA_WG_S1(2, 1, 2, 4, 8)

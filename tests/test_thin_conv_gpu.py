@@ -160,6 +160,34 @@ def test_thin_wgrad_matches_torch_and_the_general_kernel(cuda, monkeypatch, cin,
     assert torch.equal(got, again)  # fixed summation order
 
 
+WG64_CASES = [(64, 64, 3, 32, 64), (64, 128, 2, 40, 48), (128, 64, 2, 17, 33), (128, 128, 5, 64, 64), (256, 64, 1, 8, 96)]
+
+
+@pytest.mark.parametrize("cin,cout,B,H,W", WG64_CASES, ids=[f"c{c[0]}-{c[1]}_b{c[2]}_{c[3]}x{c[4]}" for c in WG64_CASES])
+def test_wgrad64_matches_torch_and_the_general_kernel(cuda, monkeypatch, cin, cout, B, H, W):
+    """conv3x3_wgrad64_kernel (64 x 64-channel blocks on maps >= 32 wide: LDS-DMA double buffer, transposed LDS reads,
+    two k groups merged through LDS) against torch.nn.grad.conv2d_weight on the bf16-rounded operands and against
+    conv_wgrad_kernel<2, 2, 2> (FFA_WGRAD64=0); ragged tiles, several splits per channel block, fixed summation order"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(cin + 3 * cout + W)
+    x = torch.randn(B, cin, H, W, generator=g)
+    dy = torch.randn(B, cout, H, W, generator=g)
+    xd, dyd = to_nhwc(x, cuda, cin), to_nhwc(dy, cuda, cout)
+    got = ops.conv_wgrad(xd, dyd, cout, cin, 3, 3, 1, 1)
+    monkeypatch.setenv("FFA_WGRAD64", "0")
+    old = ops.conv_wgrad(xd, dyd, cout, cin, 3, 3, 1, 1)
+    ref = torch.nn.grad.conv2d_weight(rq(x), (cout, cin, 3, 3), rq(dy), padding=1)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    tol = 2e-4 * scale * max(1.0, (B * H * W / 2000) ** 0.5)
+    assert (got.cpu() - ref).abs().max().item() <= tol
+    assert (got - old).abs().max().item() <= tol
+    monkeypatch.delenv("FFA_WGRAD64")
+    again = ops.conv_wgrad(xd, dyd, cout, cin, 3, 3, 1, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(got, again)
+
+
 def test_thin_wgrad_of_the_upsampled_input(cuda):
     from flairhip import ops
     g = torch.Generator().manual_seed(77)
@@ -185,6 +213,7 @@ def test_normalise_on_load_equals_the_materialised_tensor(cuda, monkeypatch, cin
     from flairhip import ops
     monkeypatch.setenv("FFA_THIN_GRID", "6")
     monkeypatch.setenv("FFA_RING_GRID", "8")
+    monkeypatch.setenv("FFA_WGRAD64", "0")  # the prologue lives in conv_wgrad_kernel: compare like with like
     g = torch.Generator().manual_seed(cin + cout + H)
     B = 2
     cip = ops.pad_channels(cin)
