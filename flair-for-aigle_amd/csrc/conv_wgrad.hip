@@ -1234,7 +1234,13 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad64_kernel(WgradArgs a) {
   const int co0 = cob * 64, ci0 = cib * 64;
   const int split = blockIdx.y;
 
-  const size_t xpb = (size_t)a.Ci * 2, ypb = (size_t)a.Co * 2;  // global bytes per pixel
+  // x = one tensor, or nearest_x2(lo) ++ skip (WgradArgs): a 64-channel block lies in ONE of the two sources (C1 is a
+  // multiple of 64); from lo, halo pixel (yy, xx) of the tile at (oy0, ox0) -- both multiples of 8 -- is lo pixel
+  // (oy0 / 2 - 1 + ((yy - 1) >> 1) + 1, ...): again a launch constant past a block-uniform origin
+  const bool two = a.C1 > 0;
+  const bool from_lo = two && ci0 < a.C1;
+  const size_t xpb = (size_t)(!two ? a.Ci : from_lo ? a.C1 : a.Ci - a.C1) * 2, ypb = (size_t)a.Co * 2;  // bytes per pixel
+  const int xW = from_lo ? a.Wi / 2 : a.Wi, xH = from_lo ? a.Hi / 2 : a.Hi;
   // per 16-byte piece of a slot (x halo, then the dy tile), fixed for the launch: offset of its source from the tile's
   // origin pixel in 16-byte units << 12 | dy piece << 11 | no piece << 10 | row << 6 | column; the swizzle is in the offset
   int pinfo[G::NHW];
@@ -1243,7 +1249,8 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad64_kernel(WgradArgs a) {
     const int p = tid + k * 512;
     if (p < G::XP) {
       const int q = p >> 3, yy = q / G::IW, xx = q % G::IW, sl = (p & 7) ^ (2 * wg64_phi(xx));
-      pinfo[k] = ((((yy * a.Wi + xx) * (int)xpb) >> 4) + sl) << 12 | (yy << 6) | xx;
+      const int py = from_lo ? ((yy - 1) >> 1) + 1 : yy, px = from_lo ? ((xx - 1) >> 1) + 1 : xx;
+      pinfo[k] = ((((py * xW + px) * (int)xpb) >> 4) + sl) << 12 | (yy << 6) | xx;
     } else if (p < G::PIECES) {
       const int q = (p - G::XP) >> 3, yy = q / G::TW, xx = q % G::TW, sl = (p & 7) ^ (2 * wg64_phi(xx));
       pinfo[k] = ((((yy * a.Wo + xx) * (int)ypb) >> 4) + sl) << 12 | (1 << 11) | (yy << 6) | xx;
@@ -1251,7 +1258,8 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad64_kernel(WgradArgs a) {
       pinfo[k] = 1 << 10;
     }
   }
-  const unsigned char* x_b = static_cast<const unsigned char*>(a.x) + ci0 * 2;
+  const unsigned char* x_b = (two && !from_lo) ? static_cast<const unsigned char*>(a.x2) + (ci0 - a.C1) * 2
+                                               : static_cast<const unsigned char*>(a.x) + ci0 * 2;
   const unsigned char* dy_b = static_cast<const unsigned char*>(a.dy) + co0 * 2;
   const unsigned char* zero = reinterpret_cast<const unsigned char*>(ffa_wgthin_zero16);
   const bool has_tail = (G::PIECES % 512 == 0) || (wave * 64 + (G::NHW - 1) * 512 < G::PIECES);
@@ -1269,7 +1277,8 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad64_kernel(WgradArgs a) {
   auto issue_tile = [&](int t, int slot) {
     int b, oy0, ox0;
     tile_origin(t, b, oy0, ox0);
-    const unsigned char* xt = x_b + ((long long)(b * a.Hi + oy0 - 1) * a.Wi + ox0 - 1) * (long long)xpb;
+    const int xoy = from_lo ? (oy0 >> 1) - 1 : oy0 - 1, xox = from_lo ? (ox0 >> 1) - 1 : ox0 - 1;
+    const unsigned char* xt = x_b + ((long long)(b * xH + xoy) * xW + xox) * (long long)xpb;
     const unsigned char* yt = dy_b + ((long long)(b * a.Ho + oy0) * a.Wo + ox0) * (long long)ypb;
 #pragma unroll
     for (int k = 0; k < G::NHW; ++k) {
@@ -1600,10 +1609,10 @@ static int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int kh, int kw, 
         return ffa_check_launch("conv_wgrad");
       }
       {
-        // conv3x3_wgrad64_kernel: whole 64-channel blocks, wide maps, single source (FFA_WGRAD64=0: conv_wgrad_kernel)
+        // conv3x3_wgrad64_kernel: whole 64-channel blocks, wide maps (FFA_WGRAD64=0: conv_wgrad_kernel)
         const char* e64 = getenv("FFA_WGRAD64");
-        if (!(e64 && e64[0] == '0') && p.wco == 2 && p.wci == 2 && p.wk == 2 && wide && p.th == 8 && a.C1 == 0 &&
-            a.pad == 1 && a.Co % 64 == 0 && a.Ci % 64 == 0 &&
+        if (!(e64 && e64[0] == '0') && p.wco == 2 && p.wci == 2 && p.wk == 2 && wide && p.th == 8 && a.C1 % 64 == 0 &&
+            (a.C1 == 0 || (a.Hi % 2 == 0 && a.Wi % 2 == 0)) && a.pad == 1 && a.Co % 64 == 0 && a.Ci % 64 == 0 &&
             (10LL * a.Wi + 34) * 2 * (a.Ci > a.Co ? a.Ci : a.Co) < (1LL << 24)) {
           hipLaunchKernelGGL(conv3x3_wgrad64_kernel, dim3(a.ncob * a.ncib, a.nsplit), dim3(512), 0, stream, a);
           return ffa_check_launch("conv3x3_wgrad64");

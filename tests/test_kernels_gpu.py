@@ -578,13 +578,13 @@ def test_conv_upcat_reports_unsupported_split(cuda):
     (64, 64, 32, 16, 16),
     (32, 0, 16, 24, 16),
     (256, 128, 128, 6, 6),
+    (64, 64, 128, 12, 32),
+    (64, 0, 64, 16, 16),
 ])
-def test_wgrad_over_virtual_upsample_concat(cuda, dtype, c1, c2, cout, Hl, Wl, monkeypatch):
-    """ffa_conv_wgrad_upcat(lo, skip, dy) == ffa_conv_wgrad(concat, dy): same slabs, same fixed-order reduce (the
-    two-source gather lives in conv_wgrad_kernel: the single-source call is kept off conv3x3_wgrad64_kernel, whose
-    summation order differs)"""
+def test_wgrad_over_virtual_upsample_concat(cuda, dtype, c1, c2, cout, Hl, Wl):
+    """ffa_conv_wgrad_upcat(lo, skip, dy) == ffa_conv_wgrad(concat, dy): same slabs, same fixed-order reduce (both calls
+    take the same kernel: conv3x3_wgrad64_kernel gathers from the two sources as well)"""
     from flairhip import ops
-    monkeypatch.setenv("FFA_WGRAD64", "0")
     g = torch.Generator().manual_seed(c1 * 3 + c2)
     B = 3
     lo = to_nhwc(torch.randn(B, c1, Hl, Wl, generator=g), dtype, cuda, c1)
