@@ -59,6 +59,11 @@ SIGNATURES = {
     "ffa_ring_pack": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ffa_conv2d_pro": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 9 + [_p]),
     "ffa_conv_wgrad_pro": (_i, [_i, _p, _p, _p, _p, _p] + [_i] * 11 + [_p, _ll, _p]),
+    "ffa_thin_eligible": (_i, [_i] * 6),
+    "ffa_thin_stat_rows": (_ll, [_i, _i, _i, _i]),
+    "ffa_thin_conv3x3": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 9 + [_p]),
+    "ffa_thin_conv3x3_pro": (_i, [_p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 9 + [_p]),
+    "ffa_thin_pack": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "ffa_thin_pack_bytes": (_ll, [_i, _i]),
     "ffa_thin_pack_desc_bytes": (_i, []),
     "ffa_thin_pack_desc_fill": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i]),

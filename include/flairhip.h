@@ -69,6 +69,27 @@ int ffa_ring_pack_desc_bytes(void);
 int ffa_ring_pack_desc_fill(void* host_desc, const float* w_oihw, const float* scale, void* dst, int O, int I,
                             int transpose, int co_rows, int ci_pitch, int dtype);
 int ffa_ring_pack_batched(int dtype, const void* descs_device, int n, ffa_stream_t stream);
+/* Thin 3x3 stride-1 pad-1 layers (bf16, <= 32 real output rows, input pitch 16 or 32: the decoder's last two blocks and the
+ * segmentation head; csrc/conv3x3_thin.hip): the whole weight operand lives in registers, the input halo arrives by
+ * LDS-DMA three tiles deep.  Replaces the same F.conv2d as ffa_conv2d for those shapes; `up` reads nearest_x2(in)
+ * (F.interpolate(scale_factor=2) in front of smp's DecoderBlock.conv1), `pool` stores the 2x2 sums of the output (its
+ * adjoint, for the transposed operand), `_pro` evaluates relu(in * scale + shift) on the staged halo.  ffa_conv2d /
+ * ffa_conv2d_upcat / ffa_conv2d_dgrad_upcat dispatch here when the operand was packed for it (ffa_conv_plan bit 13). */
+int ffa_thin_eligible(int dtype, int kh, int kw, int stride, int rows_real, int ci_pitch);
+long long ffa_thin_pack_bytes(int co_rows, int ci_pitch);
+long long ffa_thin_stat_rows(int B, int H, int W, int ci_pitch);
+int ffa_thin_conv3x3(const void* in, const void* w_thin, const float* bias, const void* residual, void* out,
+                     float* stat_partials, int B, int H, int W, int Ci, int Co, int co_rows, int relu, int up, int pool,
+                     ffa_stream_t stream);
+int ffa_thin_conv3x3_pro(const void* in, const void* w_thin, const float* bias, const void* residual, void* out,
+                         float* stat_partials, const float* pro_scale, const float* pro_shift, int B, int H, int W, int Ci,
+                         int Co, int co_rows, int relu, int up, int pool, ffa_stream_t stream);
+int ffa_thin_pack(const float* w_oihw, const float* scale, void* dst, int O, int I, int transpose, int co_rows,
+                  int ci_pitch, ffa_stream_t stream);
+int ffa_thin_pack_desc_bytes(void);
+int ffa_thin_pack_desc_fill(void* host_desc, const float* w_oihw, const float* scale, void* dst, int O, int I,
+                            int transpose, int co_rows, int ci_pitch);
+int ffa_thin_pack_batched(const void* descs_device, int n, ffa_stream_t stream);
 int ffa_conv_row_group(int kh);
 long long ffa_pack_conv_weight_bytes(int dtype, int co_rows, int ci_pitch, int kh, int kw);
 /* OIHW f32 master weight -> kernel operand.  transpose=1 builds the dgrad operand (rows = input
