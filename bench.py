@@ -245,6 +245,16 @@ class KernelTimer:
         return {k: {"bytes": v[0], "seconds": v[1], "launches": v[2]} for k, v in agg.items()}
 
 
+def pmc_traffic_source():
+    """where roofline.traffic comes from: the counters are never collected inside the timed run"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    if not found:
+        return None
+    return ("committed " + os.path.relpath(found[-1], ROOT) + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+            "of tools/collect_profiles.sh, gfx950 corrections applied by tools/pmc_summary.py); not measured in this run")
+
+
 def pmc_traffic(symbol: str):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE are
     collected in their own rocprofv3 runs, never together with timing): profiles/r01_pmc_traffic.json.
@@ -533,7 +543,7 @@ def main():
         ach = dom[1]["flops"] / dom[1]["seconds"] / 1e12
         mfma_total = sum(v["seconds"] for v in summ.values()) * (args.steps / roof_steps)
         roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom[0]),
+                    "frac": round(ach / peak, 4), "traffic": pmc_traffic(dom[0]), "traffic_source": pmc_traffic_source(),
                     "launches_per_step": dom[1]["launches"] / roof_steps,
                     "avg_launch_ms": round(dom[1]["seconds"] / dom[1]["launches"] * 1e3, 4),
                     "mfma_kernels_share_of_step": round(mfma_total / elapsed, 4)}
