@@ -329,14 +329,26 @@ class ShardedLoader:
             if isinstance(loader.sampler, DistributedSampler):
                 self.mode, self.sampler = "plain", loader.sampler
                 return
+            if loader.batch_size is None:
+                # a user batch_sampler (or batch_size=None): its batches cannot be re-derived from a DistributedSampler
+                # without knowing its constructor (Lightning re-instantiates the known ones and raises for the rest)
+                raise TypeError("ShardedLoader: a DataLoader with a custom batch_sampler / batch_size=None cannot be "
+                                "sharded automatically; build it around a DistributedSampler(num_replicas=world, rank=rank) "
+                                "yourself (it is then used as it is) or hand over an iterable of global batches")
             shuf = isinstance(loader.sampler, RandomSampler) if shuffle is None else shuffle
             self.sampler = DistributedSampler(loader.dataset, num_replicas=world, rank=rank, shuffle=shuf, seed=seed,
                                               drop_last=loader.drop_last)
+            extra = {}
+            if loader.num_workers > 0:  # only valid together with worker processes
+                extra["prefetch_factor"] = loader.prefetch_factor
+                extra["multiprocessing_context"] = loader.multiprocessing_context
+            if getattr(loader, "pin_memory_device", ""):
+                extra["pin_memory_device"] = loader.pin_memory_device
             self.inner = DataLoader(loader.dataset, batch_size=loader.batch_size, sampler=self.sampler,
                                     num_workers=loader.num_workers, collate_fn=loader.collate_fn,
                                     pin_memory=loader.pin_memory, drop_last=loader.drop_last,
                                     timeout=loader.timeout, worker_init_fn=loader.worker_init_fn,
-                                    persistent_workers=loader.persistent_workers)
+                                    persistent_workers=loader.persistent_workers, generator=loader.generator, **extra)
             self.mode = "plain"
 
     def set_epoch(self, epoch: int) -> None:
@@ -345,7 +357,22 @@ class ShardedLoader:
             self.sampler.set_epoch(epoch)
 
     def __len__(self) -> int:
-        return len(self.inner)
+        """batches this rank will yield.  Slice mode: global batches whose leading size does not divide by the world size
+        are skipped under ``drop_last`` -- counted exactly when the inner iterable says how it batches (``batch_size``,
+        ``drop_last`` and a sized ``dataset``, as a DataLoader over an iterable-free dataset does), otherwise
+        ``len(inner)`` (an upper bound by at most the one ragged batch)."""
+        n = len(self.inner)
+        if self.mode != "slice":
+            return n
+        bs, ds = getattr(self.inner, "batch_size", None), getattr(self.inner, "dataset", None)
+        if not isinstance(bs, int) or bs <= 0 or ds is None or not hasattr(ds, "__len__"):
+            return n
+        full, rem = divmod(len(ds), bs)
+        ragged = 1 if (rem and not getattr(self.inner, "drop_last", False)) else 0
+        if self.drop_last:
+            return (full if bs % self.world == 0 else 0) + (ragged if rem % self.world == 0 else 0)
+        kept = lambda m: 1 if self._bounds(m)[1] > self._bounds(m)[0] else 0
+        return full * kept(bs) + (kept(rem) if ragged else 0)
 
     def _bounds(self, n: int):
         per = n // self.world if self.drop_last else (n + self.world - 1) // self.world

@@ -219,6 +219,38 @@ def test_sharded_loader_covers_the_data_once():
         assert sorted(got) == list(range(want))
 
 
+def test_sharded_loader_forwards_loader_arguments_and_counts_kept_batches():
+    """round-2 advisor finding: the rebuilt DataLoader keeps generator / worker arguments, a custom batch_sampler is
+    refused (not silently un-collated), and len() in slice mode counts the batches that are actually yielded"""
+    sys.path.insert(0, os.path.join(ROOT, "flair-for-aigle_amd"))
+    from flairhip.distributed import ShardedLoader
+    from torch.utils.data import BatchSampler, DataLoader, SequentialSampler, TensorDataset
+    ds = TensorDataset(torch.arange(40))
+    g = torch.Generator().manual_seed(5)
+    ld = ShardedLoader(DataLoader(ds, batch_size=4, shuffle=True, generator=g, num_workers=0), 1, 2, seed=1)
+    assert ld.inner.generator is g and ld.inner.batch_size == 4 and len(ld) == len(list(ld)) == 5
+    with pytest.raises(TypeError, match="batch_sampler"):
+        ShardedLoader(DataLoader(ds, batch_sampler=BatchSampler(SequentialSampler(ds), 4, False)), 0, 2)
+
+    class Global:  # an iterable of global batches that says how it batches (what DataLoader exposes)
+        def __init__(self, n, bs, drop_last):
+            self.dataset, self.batch_size, self.drop_last = range(n), bs, drop_last
+
+        def __len__(self):
+            return len(self.dataset) // self.batch_size + (0 if self.drop_last or len(self.dataset) % self.batch_size == 0 else 1)
+
+        def __iter__(self):
+            n, bs = len(self.dataset), self.batch_size
+            for i in range(0, n - (n % bs if self.drop_last else 0), bs):
+                yield {"x": torch.arange(i, min(i + bs, n))}
+
+    for n, bs, inner_drop, world in ((30, 8, False, 4), (30, 8, True, 4), (32, 8, False, 4), (30, 6, False, 4), (28, 8, False, 4)):
+        for drop_last in (True, False):
+            for r in range(world):
+                sl = ShardedLoader(Global(n, bs, inner_drop), r, world, drop_last=drop_last)
+                assert len(sl) == len(list(sl)), (n, bs, inner_drop, drop_last, r)
+
+
 # --------------------------------------------------------------------------------------------------
 # the hook-less protocol of the hipGraph data-parallel step (GraphedTrainStep(grad_reduce=GradSync.reduce_grads)):
 # finished gradients are handed over after backward; with exact_unused a parameter that no rank produced a gradient
