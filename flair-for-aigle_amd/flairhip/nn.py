@@ -30,6 +30,13 @@ def _dw_out(conv) -> Optional[torch.Tensor]:
     buf = getattr(w, "_ffa_grad_buf", None)
     if buf is None or w.grad is not None or buf.shape != w.shape:
         return None
+    # one taker per step: a convolution applied twice in one forward would otherwise get the slot for both of its
+    # weight gradients (the second kernel overwrites the first, autograd then sums two aliases of the last one).  The
+    # state epoch moves with every optimizer step / graph replay; a second use inside it falls back to a fresh tensor,
+    # which autograd accumulates onto the slot.
+    if getattr(w, "_ffa_buf_taken", None) == _STATE_EPOCH:
+        return None
+    w._ffa_buf_taken = _STATE_EPOCH
     return buf.view(buf.shape)  # a fresh alias: autograd only adopts a gradient tensor nobody else holds
 
 
@@ -596,6 +603,10 @@ def _take_dlogit_sums(dy: torch.Tensor):
     hit = _DLOGIT_SUMS.pop(dy.data_ptr(), None)
     if hit is None or hit[0] != tuple(dy.shape) or hit[1] != dy.dtype or not dy.is_contiguous():
         return None
+    # the buffer must be exactly what the loss node handed out: if autograd accumulated a second gradient into it in
+    # place (one logits tensor feeding two losses) its version counter has moved and the sums describe one addend only
+    if dy._version != hit[3]:
+        return None
     return hit[2]
 
 
@@ -626,7 +637,7 @@ class _SoftmaxCE(torch.autograd.Function):
         sums, ctx.sums = ctx.sums, None
         out = ops.scale_inplace(dlogits, gs)
         if sums is not None:  # the sums belong to an upstream gradient of 1, like dlogits before the rescale
-            _DLOGIT_SUMS[out.data_ptr()] = (tuple(out.shape), out.dtype, sums * gs)
+            _DLOGIT_SUMS[out.data_ptr()] = (tuple(out.shape), out.dtype, sums * gs, out._version)
         return out, None, None, None, None
 
 

@@ -326,3 +326,53 @@ def test_head_bias_gradient_from_the_loss_kernel_equals_the_column_sum_pass(cuda
             assert b.abs().max().item() > 0
         else:
             assert torch.equal(a, b), k
+
+
+def test_logits_feeding_two_losses_do_not_reuse_one_losses_bias_sums(cuda):
+    """round-2 advisor finding: the loss kernel's per-class gradient sums travel to the head's backward keyed by the
+    gradient buffer's address; when ONE logits tensor feeds two losses autograd accumulates the second gradient into the
+    first buffer in place, so the address still matches while the sums describe one addend only.  The hand-over now
+    carries the buffer's version counter: the head falls back to summing the columns, and the bias gradient is the sum of
+    both losses' gradients."""
+    from flairhip import nn as hnn
+    x, t = _inputs(2, 64, 96, seed=9)
+    t2 = (t + 3) % 19
+    task, _, _ = make_pair(precision="fp32")
+    task.train()
+    batch = {MOD: x.to(cuda), TASK: t.to(cuda)}
+    crit = task.criterion[TASK]
+    grads = {}
+    for name, tgts in (("a", [t]), ("b", [t2]), ("ab", [t, t2])):
+        task.zero_grad(set_to_none=True)
+        out, _ = task.model(batch)
+        loss = sum(crit(out[TASK], tt.to(cuda)) for tt in tgts)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads[name] = {k: p.grad.detach().clone() for k, p in task.model.named_parameters()
+                       if p.grad is not None and k.endswith("segmentation_head.0.bias")}
+    (k,) = grads["ab"].keys()
+    want = grads["a"][k] + grads["b"][k]
+    assert (grads["ab"][k] - want).abs().max().item() <= 1e-5 * float(want.abs().max())
+
+
+def test_a_convolution_applied_twice_keeps_both_weight_gradients_with_a_bucket_slot(cuda):
+    """round-2 advisor finding: with a data-parallel bucket slot attached the weight-gradient kernel writes straight into
+    it; a conv used twice in one forward must not hand the slot to both of its gradients"""
+    from flairhip import nn as hnn
+    torch.manual_seed(3)
+    conv = hnn.HipConv2d(32, 32, 3, padding=1).to(cuda)
+    bn = hnn.HipBatchNorm2d(32).to(cuda)
+    x = torch.randn(2, 24, 40, 32, device=cuda).to(torch.bfloat16)
+    res = []
+    for with_slot in (False, True):
+        conv.weight.grad = None
+        bn.weight.grad = bn.bias.grad = None
+        if with_slot:
+            conv.weight._ffa_grad_buf = torch.zeros_like(conv.weight)
+        hnn.bump_state_epoch()
+        y = hnn.conv_bn_act(hnn.conv_bn_act(x, conv, bn), conv, bn)
+        y.float().square().mean().backward()
+        torch.cuda.synchronize()
+        res.append(conv.weight.grad.detach().clone())
+    assert float(res[0].abs().max()) > 0
+    assert torch.equal(res[0], res[1])
