@@ -678,3 +678,33 @@ extern "C" int ffa_mul(int dtype, const void* x, const void* m, void* y, long lo
     hipLaunchKernelGGL(mul_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, (const float*)m, (float*)y, n);
   return ffa_check_launch("mul");
 }
+
+// ---- y = (x0 + x1 + ... + x(n-1)) / divisor elementwise, n <= 4 (torch.mean(torch.stack(maps), dim=0) of FusionHandler's
+// case 3, reference flair_model.py:496-501: left-to-right f32 sum, one division, one rounding; with n = 1 and
+// divisor = n_branches it is that mean's backward)
+template <typename T>
+__global__ void mean_stack_kernel(const T* __restrict__ x0, const T* __restrict__ x1, const T* __restrict__ x2,
+                                  const T* __restrict__ x3, int n, float divisor, T* __restrict__ y, long long numel) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < numel; i += (long long)gridDim.x * blockDim.x) {
+    float acc = ffa_load_elem<T>(x0 + i);
+    if (n > 1) acc += ffa_load_elem<T>(x1 + i);
+    if (n > 2) acc += ffa_load_elem<T>(x2 + i);
+    if (n > 3) acc += ffa_load_elem<T>(x3 + i);
+    ffa_store_elem<T>(y + i, acc / divisor);
+  }
+}
+
+extern "C" int ffa_mean_stack(int dtype, const void* const* xs, int n, float divisor, void* y, long long numel,
+                              hipStream_t stream) {
+  FFA_REQUIRE(xs && y && n >= 1 && n <= 4 && numel > 0 && divisor != 0.f, "mean_stack: bad arguments (1 to 4 operands)");
+  for (int i = 0; i < n; ++i) FFA_REQUIRE(xs[i], "mean_stack: null operand");
+  const void* p[4] = {xs[0], n > 1 ? xs[1] : xs[0], n > 2 ? xs[2] : xs[0], n > 3 ? xs[3] : xs[0]};
+  const int grid = (int)((numel + 255) / 256 < 4096 ? (numel + 255) / 256 : 4096);
+  if (dtype == FFA_BF16)
+    hipLaunchKernelGGL(mean_stack_kernel<ffa_bf16>, dim3(grid), dim3(256), 0, stream, (const ffa_bf16*)p[0],
+                       (const ffa_bf16*)p[1], (const ffa_bf16*)p[2], (const ffa_bf16*)p[3], n, divisor, (ffa_bf16*)y, numel);
+  else
+    hipLaunchKernelGGL(mean_stack_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)p[0], (const float*)p[1],
+                       (const float*)p[2], (const float*)p[3], n, divisor, (float*)y, numel);
+  return ffa_check_launch("mean_stack");
+}

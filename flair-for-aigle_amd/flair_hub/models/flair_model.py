@@ -8,7 +8,7 @@ logits_aux)`` contract.  Inside, tensors are NHWC in the compute dtype (``config
 
 Scope (SURVEY.md section 8 + 8f rank 1): any number of mono-temporal modalities (AERIAL_RGBI, AERIAL-RLT_PAN,
 DEM_ELEV, SPOT_RGBI) fused per stage by FusionHandler, one or several tasks, auxiliary per-modality decoders and
-modality dropout.  The Sentinel U-TAE branch raises NotImplementedError naming what is missing.
+modality dropout.  Several Sentinel U-TAE branches without an aerial encoder average their class scores (case 3).
 """
 from __future__ import annotations
 
@@ -73,8 +73,11 @@ class FusionHandler(nn.Module):
         if not mono and len(multi) == 1:
             return feature_maps[multi[0]]
         if not mono:
-            raise NotImplementedError(f"averaging the class scores of several Sentinel branches {multi} (reference "
-                                      ":497-502) is not built; use one time-series modality or add an aerial one")
+            # case 3 (:496-501): several time-series branches, no aerial encoder -> the mean of their class-score maps
+            # (already resized to the label size, :390-392); one pass, f32 sum, one rounding
+            if len(multi) > 4:
+                raise NotImplementedError(f"mean over {len(multi)} time-series branches (ffa_mean_stack takes four)")
+            return hnn.mean_stack([feature_maps[k] for k in multi])
         # case 4 (:504-547): a U-TAE branch contributes its decoder maps, coarse to fine, one per aerial stage (the
         # reference zips them in list order, flair_model.py:514-531); every map is resized to the stage it meets
         def strip(maps):  # the [input, 0-channel placeholder] pair of a transformer-style encoder (:508-518)

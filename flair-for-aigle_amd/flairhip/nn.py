@@ -719,6 +719,25 @@ def fusion_conv1x1(xs, splits, conv: HipConv2d):
     return _FusionConv1x1.apply(conv.weight, conv.bias, conv, tuple(splits), *xs)
 
 
+class _MeanStack(torch.autograd.Function):
+    """torch.mean(torch.stack(xs), 0) of same-shaped NHWC maps (FusionHandler case 3)"""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        ctx.n = len(xs)
+        return ops.mean_stack([x.contiguous() for x in xs])
+
+    @staticmethod
+    def backward(ctx, g):
+        gi = ops.mean_stack([_as_nhwc_grad(g)], divisor=ctx.n)
+        return tuple(gi for _ in range(ctx.n))  # the same tensor for every branch: nobody writes a gradient in place
+
+
+def mean_stack(xs):
+    xs = list(xs)
+    return xs[0] if len(xs) == 1 else _MeanStack.apply(*xs)
+
+
 def max_pool(x):
     return _MaxPool.apply(x)
 

@@ -1357,6 +1357,23 @@ def temporal_aggregate_bwd(x: torch.Tensor, attn: torch.Tensor, pad: torch.Tenso
     return dx, dattn
 
 
+def mean_stack(xs, divisor: Optional[float] = None) -> torch.Tensor:
+    """(xs[0] + ... + xs[-1]) / divisor (default: their number) -- torch.mean(torch.stack(xs), 0) in one pass"""
+    import ctypes as C
+    xs = list(xs)
+    if not 1 <= len(xs) <= 4:
+        raise ValueError("mean_stack: 1 to 4 operands")
+    x0 = xs[0]
+    for x in xs:
+        if x.shape != x0.shape or x.dtype != x0.dtype or not x.is_contiguous():
+            raise ValueError("mean_stack: operands must be contiguous tensors of one shape and dtype")
+    y = torch.empty_like(x0)
+    ptrs = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+    _l.check(_l.load().ffa_mean_stack(_dt(x0), ptrs, len(xs), float(len(xs) if divisor is None else divisor), y.data_ptr(),
+                                      x0.numel(), _stream()), "mean_stack")
+    return y
+
+
 def mul(x: torch.Tensor, m: torch.Tensor) -> torch.Tensor:
     if x.shape != m.shape or x.dtype != m.dtype or not x.is_contiguous() or not m.is_contiguous():
         raise ValueError("mul: operands must be contiguous tensors of one shape and dtype")

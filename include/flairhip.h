@@ -226,6 +226,10 @@ int ffa_temporal_aggregate_bwd(int dtype, const void* x, const float* attn, cons
                                ffa_stream_t stream);
 /* y = x * m elementwise (nn.Dropout with a pre-scaled keep mask; its own backward) */
 int ffa_mul(int dtype, const void* x, const void* m, void* y, long long n, ffa_stream_t stream);
+/* y = (xs[0] + ... + xs[n-1]) / divisor elementwise, 1 <= n <= 4 (host array of device pointers): FusionHandler's
+ * case 3, torch.mean(torch.stack([maps of several time-series branches]), dim=0), flair_hub/models/flair_model.py:496-501;
+ * with n = 1, divisor = branches: its backward */
+int ffa_mean_stack(int dtype, const void* const* xs, int n, float divisor, void* y, long long numel, ffa_stream_t stream);
 
 /* ---- Swin-Transformer encoder + UPerNet decoder (the reference's default `swin_*-upernet` architecture:
  *      configs/train/config_models.yaml:5, configs/config_model_zonal_segmentation.yaml:26, resolved through

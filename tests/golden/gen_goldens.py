@@ -15,7 +15,7 @@ small stand-in modules injected into sys.modules for those imports ONLY inside t
 Only data (inputs + the reference's outputs) is written; no reference source is copied.  The fixtures are
 committed; this script is not run on the GPU box (the reference does not travel).
 
-Usage:  python tests/golden/gen_goldens.py [fusion | sentinel | swin]
+Usage:  python tests/golden/gen_goldens.py [fusion | sentinel | sentinel_mean | swin]
 """
 from __future__ import annotations
 
@@ -496,6 +496,66 @@ def gen_sentinel(path_json, path_npz):
     json.dump(info, open(path_json, "w"), indent=1)
 
 
+def gen_sentinel_mean(path_json, path_npz):
+    """FusionHandler case 3 (flair_model.py:496-501): SEVERAL time-series branches and no aerial encoder -- the
+    reference averages their class-score maps (each bilinearly resized to the label size, :390-392) and, with two tasks,
+    puts one 1x1 head per task on the mean (:420-424).  SENTINEL2_TS (10 bands, T = 5, one padded date) +
+    SENTINEL1-ASC_TS (2 bands, T = 3): evaluation forward, then one SegmentationTask.step + backward with the U-TAE
+    dropouts set to 0 on the instances."""
+    from flair_hub.tasks.module_setup import build_segmentation_module
+    cfgs = _load_cfgs()
+    g = torch.Generator().manual_seed(59)
+    S2, S1 = "SENTINEL2_TS", "SENTINEL1-ASC_TS"
+    cfg = cfgs.fusion_unet_config(precision="fp32", aux_loss=False)
+    cfg["modalities"]["inputs"] = {m: False for m in cfg["modalities"]["inputs"]}
+    cfg["modalities"]["inputs"][S2] = True
+    cfg["modalities"]["inputs"][S1] = True
+    cfg["modalities"]["inputs_channels"][S2] = list(range(1, 11))
+    cfg["modalities"]["inputs_channels"][S1] = [1, 2]
+    cfg["modalities"]["aux_loss"] = {m: False for m in cfg["modalities"]["aux_loss"]}
+    torch.manual_seed(2025)
+    task = build_segmentation_module(cfg, {S2: 10, S1: 10}, stage="train")
+    task.model.load_state_dict(_fill_mixed(task.model.state_dict()))
+    x2 = torch.randn(2, 5, 10, 10, 10, generator=g)
+    x2[1, 4] = 0.0
+    p2 = torch.sort(torch.randint(0, 365, (2, 5), generator=g), dim=1).values.float()
+    x1 = torch.randn(2, 3, 2, 10, 10, generator=g)
+    p1 = torch.sort(torch.randint(0, 365, (2, 3), generator=g), dim=1).values.float()
+    tc = torch.randint(0, 19, (2, 40, 40), generator=g)
+    tl = torch.randint(0, 23, (2, 40, 40), generator=g)
+    batch = {S2: x2, S2.replace("TS", "DATES"): p2, S1: x1, S1.replace("TS", "DATES"): p1,
+             "AERIAL_LABEL-COSIA": torch.nn.functional.one_hot(tc, 19).permute(0, 3, 1, 2).float(), "ALL_LABEL-LPIS": tl}
+    task.eval()
+    with torch.no_grad():
+        lt, la = task.model(batch)
+    out = dict(x_s2=x2.numpy(), pos_s2=p2.numpy(), x_s1=x1.numpy(), pos_s1=p1.numpy(),
+               t_cosia=tc.numpy().astype(np.uint8), t_lpis=tl.numpy().astype(np.uint8),
+               logits_cosia=lt["AERIAL_LABEL-COSIA"].numpy(), logits_lpis=lt["ALL_LABEL-LPIS"].numpy())
+    for m in (S2, S1):
+        te = task.model.encoders[m].temporal_encoder
+        te.dropout.p = 0.0
+        te.attention_heads.attention.dropout.p = 0.0
+    task.train()
+    loss, preds, _ = task.step(batch, training=True)
+    loss.backward()
+    named = dict(task.model.named_parameters())
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in named.values() if p.grad is not None))
+    sampled = [f"encoders.{S2}.in_conv.conv.conv.0.weight", f"encoders.{S1}.in_conv.conv.conv.0.weight",
+               f"encoders.{S1}.temporal_encoder.attention_heads.Q", "main_decoders.ALL_LABEL-LPIS.weight",
+               "main_decoders.AERIAL_LABEL-COSIA.bias"]
+    out.update({"grad__" + k: named[k].grad.numpy() for k in sampled})
+    info = {"logit_keys": sorted(lt.keys()), "aux_keys": sorted(la.keys()),
+            "state_dict_keys": sorted(task.model.state_dict().keys()),
+            "multitemp_model": {k: cfg["models"]["multitemp_model"][k] for k in ("encoder_widths", "decoder_widths", "out_conv")},
+            "train": {"loss": hexf(loss.item()), "grad_norm": float(gn),
+                      "grad_norms": {k: float(p.grad.double().norm()) for k, p in named.items() if p.grad is not None},
+                      "unused_parameters": sorted(k for k, p in named.items() if p.grad is None)}}
+    np.savez_compressed(path_npz, **out)
+    json.dump(info, open(path_json, "w"), indent=1)
+    print("  sentinel mean:", {k: tuple(v.shape) for k, v in lt.items()}, f"train loss {loss.item():.6f} grad-norm {float(gn):.6f}, "
+          f"{len(info['train']['unused_parameters'])} parameters without gradient")
+
+
 SWIN_SAMPLED_GRADS = ["fusion_handler.conv_f.0.weight", "fusion_handler.conv_f.1.weight",
                       "encoders.DEM_ELEV.seg_model.model.layers_1.blocks.1.attn.relative_position_bias_table",
                       "encoders.DEM_ELEV.seg_model.model.patch_embed.proj.weight",
@@ -570,6 +630,8 @@ def main():
     install_stubs()
     if sys.argv[1:] == ["swin"]:
         return gen_swin(os.path.join(HERE, "swin_two_mod.json"), os.path.join(HERE, "swin_two_mod.npz"))
+    if sys.argv[1:] == ["sentinel_mean"]:
+        return gen_sentinel_mean(os.path.join(HERE, "sentinel_mean.json"), os.path.join(HERE, "sentinel_mean.npz"))
     if sys.argv[1:] == ["sentinel"]:
         return gen_sentinel(os.path.join(HERE, "sentinel.json"), os.path.join(HERE, "sentinel.npz"))
     if sys.argv[1:] == ["fusion"]:  # regenerate only the multi-modality fixture
