@@ -388,12 +388,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     # FFA_BENCH_BACKEND=gloo lets the multi-rank flow be rehearsed on a one-GPU box (ranks then share cuda:0)
     backend = os.environ.get("FFA_BENCH_BACKEND", "nccl")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # read once, when the GPU runtime initialises (next line)
     local_dev = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
+    # FFA_BENCH_FORCE_DDP=1 (one process): run the N > 1 PROGRAM -- graph(fwd + bwd) -> bucketed RCCL all-reduce ->
+    # graph(AdamW) -- in a one-rank RCCL group, so that a one-GPU box executes exactly what the multi-GPU launch runs
+    ddp = world > 1 or os.environ.get("FFA_BENCH_FORCE_DDP", "0") == "1"
+    if ddp:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend, rank=0, world_size=1, **({"device_id": dev} if backend == "nccl" else {}))
+        elif backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # RCCL; one process per GPU
         else:
             dist.init_process_group(backend)
@@ -410,7 +417,7 @@ def main():
     task.train()
     opt_cfg = task.configure_optimizers()
     optimizer, scheduler = opt_cfg["optimizer"], opt_cfg["lr_scheduler"]["scheduler"]
-    sync = GradSync(task.model)
+    sync = GradSync(task.model, always_sync=(ddp and world == 1))
 
     g = torch.Generator(device=dev).manual_seed(2025 + rank)
     B, S = args.batch, args.tile
@@ -425,7 +432,7 @@ def main():
         loss = task.training_step(batch, i)
         optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        if sync._handles or world == 1:
+        if sync._handles or not ddp:
             sync.finish()  # all-reduces were issued from the autograd hooks, underneath backward
         else:  # hook-less GradSync of the graph mode: hand the finished gradients over
             ps = [p for p in task.model.parameters() if p.grad is not None]
@@ -438,23 +445,23 @@ def main():
     # multi process: THE SAME captured kernels as two graphs with the collectives between them -- graph(forward + loss +
     # backward, weight gradients written into the flat buckets) -> bucketed RCCL all-reduce -> graph(AdamW)
     # (flairhip.graph.GraphedTrainStep); --ddp-eager: eager step, all-reduces from autograd hooks, overlapped with backward
-    use_graph = (not args.no_graph) and (world == 1 or not args.ddp_eager)
+    use_graph = (not args.no_graph) and (not ddp or not args.ddp_eager)
     graphed = None
     if use_graph:
         from flairhip.graph import GraphedTrainStep
         try:
-            if world == 1:
+            if not ddp:
                 graphed = GraphedTrainStep(task, optimizer, batch, warmup_steps=3, after_step=scheduler.step)
             else:
                 sync.remove()
-                sync = GradSync(task.model, hooks=False, broadcast_from_rank0=False)
+                sync = GradSync(task.model, hooks=False, broadcast_from_rank0=False, always_sync=(world == 1))
                 graphed = GraphedTrainStep(task, optimizer, batch, warmup_steps=3, after_step=scheduler.step,
                                            grad_reduce=sync.reduce_grads)
         except Exception as e:  # capture is an optimisation, never a requirement
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             use_graph = False
-            if world > 1:
-                sync = GradSync(task.model, broadcast_from_rank0=False)
+            if ddp:
+                sync = GradSync(task.model, broadcast_from_rank0=False, always_sync=(world == 1))
     if use_graph and os.environ.get("FFA_BENCH_COPY_INPUTS", "0") != "1":
         # the synthetic batch lives in the graph's own static input buffers (GraphedTrainStep copies a batch it is handed
         # only when it sits elsewhere): like the eager step, the replay reads inputs that are already where the kernels
@@ -562,8 +569,8 @@ def main():
                                    f"train step (BASELINE.json configs[{1 if world == 1 else 2}])",
                        "global_batch": B * world, "tile": S, "parallelism": f"dp{world}"},
             "final_loss": round(final_loss, 5), "hip_graph": bool(use_graph),
-            "step_mode": ("hipgraph(whole step)" if world == 1 else "hipgraph(fwd+bwd) -> bucketed all-reduce -> hipgraph(adamw)")
-                         if use_graph else ("eager" if world == 1 else "eager, all-reduce from autograd hooks"),
+            "step_mode": ("hipgraph(whole step)" if not ddp else "hipgraph(fwd+bwd) -> bucketed all-reduce -> hipgraph(adamw)")
+                         if use_graph else ("eager" if not ddp else "eager, all-reduce from autograd hooks"),
             "ms_per_step_eager": round(elapsed_eager / args.steps * 1e3, 3),
             "roofline": roofline,
         }
@@ -614,7 +621,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(B=2)
             out["cpu_baseline_b8"] = cpu_baseline(B=8)  # B = 2 (config 1) and B = 8
         print(json.dumps(out))
-    if world > 1:
+    if ddp:
         dist.destroy_process_group()
 
 

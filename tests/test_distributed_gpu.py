@@ -152,6 +152,48 @@ def test_bucket_protocol_over_rccl_on_one_gpu(cuda, tmp_path):
         assert torch.equal(v, res["rccl"][k]), k
 
 
+def _rccl_graph_worker(rank, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "flair-for-aigle_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from flairhip.distributed import GradSync
+    from flairhip.graph import GraphedTrainStep
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    results = {}
+    for mode in ("graph", "graph+rccl"):
+        task = _build().to(dev)
+        task.train()
+
+        class _T:
+            estimated_stepping_batches = STEPS + 4
+        task.trainer = _T()
+        opt = task.configure_optimizers()["optimizer"]
+        batches = [{k: v[:B_RANK].to(dev) for k, v in gb.items()} for gb in _global_batches()]
+        sync = GradSync(task.model, hooks=False, always_sync=(mode == "graph+rccl"), exact_unused=True)
+        stepper = GraphedTrainStep(task, opt, batches[0], warmup_steps=2, grad_reduce=sync.reduce_grads)
+        losses = [stepper(b).item() for b in batches]
+        torch.cuda.synchronize()
+        results[mode] = ({k: v.detach().cpu() for k, v in task.model.named_parameters()}, losses)
+    torch.save(results, os.path.join(out_dir, "rccl_graph.pt"))
+    dist.destroy_process_group()
+
+
+def test_the_multi_gpu_program_over_rccl_on_one_gpu(cuda, tmp_path):
+    """What `bench.py --gpus N` and HipTrainer run for N > 1 -- hipGraph(forward + backward) -> GradSync.reduce_grads
+    (bucketed all-reduce on RCCL's stream, stream-side waits, gradients already inside the buckets) -> hipGraph(AdamW) --
+    in a one-rank RCCL group: equal, bit for bit, to the same two graphs without the collectives."""
+    mp.spawn(_rccl_graph_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(tmp_path / "rccl_graph.pt")
+    (wa, la), (wb, lb) = res["graph"], res["graph+rccl"]
+    assert la == lb
+    for k in wa:
+        assert torch.equal(wa[k], wb[k]), k
+
+
 SWIN = "swin_tiny_patch4_window7_224-upernet"
 
 
