@@ -28,6 +28,16 @@ import torch
 from . import nn as hnn
 
 
+def _capture_mode() -> str:
+    """cudaStreamCaptureMode of the captures in this module.  With a process group alive, ProcessGroupNCCL's watchdog
+    THREAD polls the completion events of earlier collectives (hipEventQuery); under the default "global" mode any such
+    call from any thread while this thread captures is an error and takes the process down ("operation not permitted
+    when stream is capturing" -- hit on the one-rank RCCL rehearsal of the data-parallel graph step, a race on when the
+    watchdog last looked).  "thread_local" keeps the safety net for the capturing thread and leaves other threads alone."""
+    import torch.distributed as dist
+    return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+
+
 def make_capturable(optimizer: torch.optim.Optimizer) -> None:
     """Adam / AdamW: device-resident step counters and learning rate, as graph capture requires."""
     for g in optimizer.param_groups:
@@ -71,7 +81,7 @@ class GraphedTrainStep:
         # every packed operand counts as stale from here: the pack kernels MUST be part of the captured step (a plan
         # that happens to be fresh at capture time would otherwise leave the replays training on frozen operands)
         hnn.bump_state_epoch()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             loss = task.training_step(self.static_batch, 0)
             loss.backward()
             if grad_reduce is None:
@@ -88,7 +98,7 @@ class GraphedTrainStep:
             # those tensors: the same addresses in every later step
             grad_reduce(self.params, self.static_grads)
             self.opt_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.opt_graph):
+            with torch.cuda.graph(self.opt_graph, capture_error_mode=_capture_mode()):
                 optimizer.step()
 
     def _eager_step(self, i: int):
@@ -140,7 +150,7 @@ class GraphedCall:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             self.static_out = fn(self.static_in)
 
     def __call__(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:

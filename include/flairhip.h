@@ -231,6 +231,14 @@ int ffa_mul(int dtype, const void* x, const void* m, void* y, long long n, ffa_s
  * with n = 1, divisor = branches: its backward */
 int ffa_mean_stack(int dtype, const void* const* xs, int n, float divisor, void* y, long long numel, ffa_stream_t stream);
 
+/* ---- optimizer step: Adam / AdamW over all parameter tensors (csrc/optim.hip).  Replaces torch.optim.AdamW / Adam as
+ *      built at flair_hub/tasks/tasks_module.py:385-389 (same update, same state tensors: exp_avg, exp_avg_sq, a
+ *      per-parameter device step counter that already counts this update).  Host arrays of device pointers, one entry per
+ *      f32 parameter tensor; lr is a device scalar; ceil(n / 72) launches, descriptors ride in the kernel arguments. */
+int ffa_adamw_multi(int n_tensors, void* const* p, const void* const* g, void* const* m, void* const* v,
+                    const void* const* step, const long long* numel, const float* lr, double beta1, double beta2,
+                    float eps, float weight_decay, int decoupled, int maximize, ffa_stream_t stream);
+
 /* ---- Swin-Transformer encoder + UPerNet decoder (the reference's default `swin_*-upernet` architecture:
  *      configs/train/config_models.yaml:5, configs/config_model_zonal_segmentation.yaml:26, resolved through
  *      flair_hub/models/monotemp_model.py:64-92 by smp.create_model("upernet", "tu-swin_...")).
