@@ -26,6 +26,7 @@
 //   halo      [k-step plane][halo pixel][32 B], halves swapped when bit 3 of the pixel's x is set; plane stride
 //             = 64 mod 128 bytes -> conflict-free ds_read_b128 for 32 pixels of a row and conflict-free ds_write_b128
 #include "ffa_common.h"
+#include <hip/hip_ext.h>
 
 #include <stdlib.h>
 
@@ -1019,6 +1020,12 @@ static RingPlan ring_plan(int B, int H, int W, int co_rows) {
 
 template <int WCO, int WPX, int NT, int TH, int TW, int OCC>
 static int ring16_launch(const Ring3Args& a, int grid, hipStream_t stream) {
+  hipEvent_t ts, te;  // measurement session open (bench.py): the kernel's own duration from launch-attached events
+  if (!a.pro_sc && ffa_ktime_next(WCO == 2 ? FFA_KT_RING16_128CO : (TW == 32 ? FFA_KT_RING16_8x32 : FFA_KT_RING16_16x16), &ts, &te)) {
+    hipExtLaunchKernelGGL((conv3x3_ring16_kernel<WCO, WPX, NT, TH, TW, OCC, false>), dim3(grid), dim3(64 * WCO * WPX), 0,
+                          stream, ts, te, 0, a);
+    return ffa_check_launch("conv3x3_ring16");
+  }
   if (a.pro_sc)
     hipLaunchKernelGGL((conv3x3_ring16_kernel<WCO, WPX, NT, TH, TW, OCC, true>), dim3(grid), dim3(64 * WCO * WPX), 0,
                        stream, a);

@@ -14,6 +14,7 @@
 // subset of the spatial tiles and writes its f32 partial slab; wgrad_reduce_kernel sums the
 // slabs in fixed order (deterministic, no float atomics) and writes the OIHW f32 gradient.
 #include "ffa_common.h"
+#include <hip/hip_ext.h>
 
 #include <stdlib.h>
 
@@ -1614,7 +1615,11 @@ static int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int kh, int kw, 
         if (!(e64 && e64[0] == '0') && p.wco == 2 && p.wci == 2 && p.wk == 2 && wide && p.th == 8 && a.C1 % 64 == 0 &&
             (a.C1 == 0 || (a.Hi % 2 == 0 && a.Wi % 2 == 0)) && a.pad == 1 && a.Co % 64 == 0 && a.Ci % 64 == 0 &&
             (10LL * a.Wi + 34) * 2 * (a.Ci > a.Co ? a.Ci : a.Co) < (1LL << 24)) {
-          hipLaunchKernelGGL(conv3x3_wgrad64_kernel, dim3(a.ncob * a.ncib, a.nsplit), dim3(512), 0, stream, a);
+          hipEvent_t ts, te;
+          if (ffa_ktime_next(FFA_KT_WGRAD64, &ts, &te))
+            hipExtLaunchKernelGGL(conv3x3_wgrad64_kernel, dim3(a.ncob * a.ncib, a.nsplit), dim3(512), 0, stream, ts, te, 0, a);
+          else
+            hipLaunchKernelGGL(conv3x3_wgrad64_kernel, dim3(a.ncob * a.ncib, a.nsplit), dim3(512), 0, stream, a);
           return ffa_check_launch("conv3x3_wgrad64");
         }
       }

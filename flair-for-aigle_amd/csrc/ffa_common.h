@@ -25,6 +25,12 @@
 
 void ffa_set_error(const char* fmt, ...);
 int ffa_check_launch(const char* what);
+// kernel timing session (ffa_runtime.hip): true + an event pair when this thread has one open
+bool ffa_ktime_next(int tag, hipEvent_t* start, hipEvent_t* stop);
+#define FFA_KT_RING16_8x32 1
+#define FFA_KT_RING16_16x16 2
+#define FFA_KT_RING16_128CO 4
+#define FFA_KT_WGRAD64 16
 
 #define FFA_REQUIRE(cond, ...)                 \
   do {                                         \

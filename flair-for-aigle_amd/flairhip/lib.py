@@ -118,6 +118,8 @@ SIGNATURES = {
     "ffa_temporal_aggregate_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "ffa_mul": (_i, [_i, _p, _p, _p, _ll, _p]),
     "ffa_mean_stack": (_i, [_i, _p, _i, C.c_float, _p, _ll, _p]),
+    "ffa_ktime_begin": (_i, [_i]),
+    "ffa_ktime_end": (_i, [_p, _p, _i]),
     "ffa_adamw_multi": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, C.c_double, C.c_double, C.c_float, C.c_float, _i, _i, _p]),
     "ffa_bn_workspace_bytes": (_ll, [_i]),
     "ffa_bn_stats": (_i, [_i, _p, _ll, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _ll, _p]),

@@ -231,6 +231,14 @@ int ffa_mul(int dtype, const void* x, const void* m, void* y, long long n, ffa_s
  * with n = 1, divisor = branches: its backward */
 int ffa_mean_stack(int dtype, const void* const* xs, int n, float divisor, void* y, long long numel, ffa_stream_t stream);
 
+/* ---- measurement only: kernel timing session.  Between ffa_ktime_begin(max_launches) and ffa_ktime_end() the 3x3 MFMA
+ *      launches of the process (ffa_conv2d on the ring operand, ffa_conv_wgrad on 64-channel blocks) carry their
+ *      own start / stop events (hipExtLaunchKernelGGL): ffa_ktime_end waits for them and returns, in launch order, the
+ *      kernels' durations in milliseconds and a tag (1: ring16 8x32 tiles, 2: ring16 16x16, 4: ring16 128-co blocks,
+ *      16: wgrad64); its return value is the number of timed launches.  Not for use under stream capture. */
+int ffa_ktime_begin(int max_launches);
+int ffa_ktime_end(float* ms, int* tags, int cap);
+
 /* ---- optimizer step: Adam / AdamW over all parameter tensors (csrc/optim.hip).  Replaces torch.optim.AdamW / Adam as
  *      built at flair_hub/tasks/tasks_module.py:385-389 (same update, same state tensors: exp_avg, exp_avg_sq, a
  *      per-parameter device step counter that already counts this update).  Host arrays of device pointers, one entry per

@@ -121,3 +121,25 @@ def test_ring_prologue_equals_materialised_batchnorm_relu(cuda, monkeypatch, dty
     got = ops.conv3x3_ring(x, pw, cop, pro_scale=sc, pro_shift=sh)
     torch.cuda.synchronize()
     assert torch.equal(got, ref)
+
+
+def test_kernel_timing_session_times_the_ring_launch_itself(cuda):
+    """ffa_ktime_begin / _end (bench.py's roofline pass): inside a session the ring16 launch carries its own start / stop
+    events; the result is unchanged, one timing per launch comes back with the kernel's tag, and a session cannot nest."""
+    import ctypes as C
+    from flairhip import lib as L, ops
+    lib = L.load()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 64, 128, generator=g).to(cuda).to(torch.bfloat16)
+    w = (torch.randn(128, 128, 3, 3, generator=g) / 34.0).to(cuda)
+    pw = ops.pack_conv_weight(w, torch.bfloat16, 1, 128)
+    ref = ops.conv2d(x, pw, 1, 128)
+    L.check(lib.ffa_ktime_begin(8), "ktime_begin")
+    assert lib.ffa_ktime_begin(8) != 0  # no nesting
+    got = [ops.conv2d(x, pw, 1, 128) for _ in range(3)]
+    ms, tags = (C.c_float * 8)(), (C.c_int * 8)()
+    n = lib.ffa_ktime_end(ms, tags, 8)
+    assert n == 3 and all(tags[i] == 1 for i in range(3)) and all(0.0 < ms[i] < 5.0 for i in range(3))
+    assert all(torch.equal(t, ref) for t in got)
+    assert lib.ffa_ktime_end(ms, tags, 8) < 0  # no session open any more
+    assert torch.equal(ops.conv2d(x, pw, 1, 128), ref)
