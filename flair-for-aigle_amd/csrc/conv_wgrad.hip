@@ -1197,8 +1197,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_thin_wgrad_kernel(WgradArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// 64 x 64-channel blocks of the bulk of the network (bf16, 3x3 stride 1 pad 1, Co and Ci multiples of 64, maps at least 32
-// wide; round 3): conv3x3_thin_wgrad_kernel's recipe -- v_mfma_f32_16x16x32_bf16 on transposed LDS reads, operands by
+// 64 x 64-channel blocks of the bulk of the network (bf16, 3x3 stride 1 pad 1, Co and Ci multiples of 64; 8 x 32-pixel
+// tiles, or 16 x 16 on maps narrower than 32; round 3): conv3x3_thin_wgrad_kernel's recipe -- v_mfma_f32_16x16x32_bf16 on transposed LDS reads, operands by
 // LDS-DMA into a second slot while the first is multiplied, no LDS store phase, no staging registers -- at the channel
 // decomposition of conv_wgrad_kernel<2, 2, 2>: eight waves = two k groups (rows 0-3 / 4-7 of the 8 x 32 tile) x (2 co x
 // 2 ci) sub-tiles of 32 x 32 channels x 9 taps (144 accumulator registers), one block per CU, the k groups merged
@@ -1208,8 +1208,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_thin_wgrad_kernel(WgradArgs a)
 // bit 3 << 1 of the pixel's column in its image: conflict-free ds_read_b64_tr_b16 for every tap shift (enumerated),
 // applied on the DMA source address.
 
+template <int TW_>
 struct Wg64Geom {
-  static constexpr int TH = 8, TW = 32, IH = 10, IW = 34;
+  static constexpr int TW = TW_, TH = 256 / TW_, IH = TH + 2, IW = TW + 2;
+  static constexpr int RS = 32 / TW;  // image rows per 32-pixel k-step: 1 (8 x 32 tiles) or 2 (16 x 16 tiles)
   static constexpr int XP = IH * IW * 8, YP = TH * TW * 8;  // 16-byte pieces
   static constexpr int PIECES = XP + YP;
   static constexpr int NHW = (PIECES + 511) / 512;
@@ -1217,18 +1219,20 @@ struct Wg64Geom {
   static constexpr int SLOT = PIECES * 16;
   static constexpr int ACC_BYTES = 144 * 64 * 4;  // one wave
   static constexpr int LDS_BYTES = (2 * SLOT > 4 * ACC_BYTES) ? 2 * SLOT : 4 * ACC_BYTES;
+  static_assert(TW == 32 || TW == 16, "tile width");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 __device__ __forceinline__ int wg64_phi(int px) { return ((px >> 1) & 1) | (((px >> 3) & 1) << 1); }
 
+template <int TW>
 __global__ void __launch_bounds__(512) conv3x3_wgrad64_kernel(WgradArgs a) {
-  using G = Wg64Geom;
+  using G = Wg64Geom<TW>;
   __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kgp = wave >> 2;             // k group: tile rows 4 * kgp .. 4 * kgp + 3
+  const int kgp = wave >> 2;             // k group: k-steps (32 pixels: one tile row, or two at TW = 16) 4 * kgp .. + 3
   const int wco = (wave >> 1) & 1, wci = wave & 1;
   const int li = lane & 15, kg = lane >> 4;
   const int cib = blockIdx.x % a.ncib, cob = blockIdx.x / a.ncib;
@@ -1243,7 +1247,7 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad64_kernel(WgradArgs a) {
   const size_t xpb = (size_t)(!two ? a.Ci : from_lo ? a.C1 : a.Ci - a.C1) * 2, ypb = (size_t)a.Co * 2;  // bytes per pixel
   const int xW = from_lo ? a.Wi / 2 : a.Wi, xH = from_lo ? a.Hi / 2 : a.Hi;
   // per 16-byte piece of a slot (x halo, then the dy tile), fixed for the launch: offset of its source from the tile's
-  // origin pixel in 16-byte units << 12 | dy piece << 11 | no piece << 10 | row << 6 | column; the swizzle is in the offset
+  // origin pixel in 16-byte units << 13 | dy piece << 12 | no piece << 11 | row << 6 | column; the swizzle is in the offset
   int pinfo[G::NHW];
 #pragma unroll
   for (int k = 0; k < G::NHW; ++k) {
@@ -1251,12 +1255,12 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad64_kernel(WgradArgs a) {
     if (p < G::XP) {
       const int q = p >> 3, yy = q / G::IW, xx = q % G::IW, sl = (p & 7) ^ (2 * wg64_phi(xx));
       const int py = from_lo ? ((yy - 1) >> 1) + 1 : yy, px = from_lo ? ((xx - 1) >> 1) + 1 : xx;
-      pinfo[k] = ((((py * xW + px) * (int)xpb) >> 4) + sl) << 12 | (yy << 6) | xx;
+      pinfo[k] = ((((py * xW + px) * (int)xpb) >> 4) + sl) << 13 | (yy << 6) | xx;
     } else if (p < G::PIECES) {
       const int q = (p - G::XP) >> 3, yy = q / G::TW, xx = q % G::TW, sl = (p & 7) ^ (2 * wg64_phi(xx));
-      pinfo[k] = ((((yy * a.Wo + xx) * (int)ypb) >> 4) + sl) << 12 | (1 << 11) | (yy << 6) | xx;
+      pinfo[k] = ((((yy * a.Wo + xx) * (int)ypb) >> 4) + sl) << 13 | (1 << 12) | (yy << 6) | xx;
     } else {
-      pinfo[k] = 1 << 10;
+      pinfo[k] = 1 << 11;
     }
   }
   const unsigned char* x_b = (two && !from_lo) ? static_cast<const unsigned char*>(a.x2) + (ci0 - a.C1) * 2
@@ -1284,19 +1288,19 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad64_kernel(WgradArgs a) {
 #pragma unroll
     for (int k = 0; k < G::NHW; ++k) {
       const int info = pinfo[k];
-      const int yy = (info >> 6) & 15, xx = info & 63;
+      const int yy = (info >> 6) & 31, xx = info & 63;
       // pieces 0 .. XP-1 are x: k < XP / 512 all x, k > XP / 512 all dy, one mixed k
       const bool mixed = (k == G::XP / 512) && (G::XP % 512 != 0);
-      const bool is_dy = mixed ? (info & (1 << 11)) != 0 : (k * 512 >= G::XP);
+      const bool is_dy = mixed ? (info & (1 << 12)) != 0 : (k * 512 >= G::XP);
       const int oy = yy + (is_dy ? oy0 : oy0 - 1), ox = xx + (is_dy ? ox0 : ox0 - 1);
       const bool valid = (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo;
-      const unsigned char* src = valid ? (is_dy ? yt : xt) + (size_t)(((unsigned)info >> 12) << 4) : zero;
+      const unsigned char* src = valid ? (is_dy ? yt : xt) + (size_t)(((unsigned)info >> 13) << 4) : zero;
       const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(
           smem + slot * G::SLOT + (wave * 64 + k * 512) * 16);
       if (k + 1 < G::NHW || G::PIECES % 512 == 0) {
         wgthin_dma16(src, dst);
       } else if (has_tail) {
-        if (!(info & (1 << 10))) wgthin_dma16(src, dst);
+        if (!(info & (1 << 11))) wgthin_dma16(src, dst);
       }
       __builtin_amdgcn_sched_barrier(0);  // one piece's address registers at a time (144 accumulators are live)
     }
@@ -1314,15 +1318,17 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad64_kernel(WgradArgs a) {
   // k-step, 8-byte segment li & 3 of a 16-channel tile; physical 16-byte slot = (2 * tile + (li >> 1 & 1)) ^ 2 * phi(pixel)
   const int kpx = 8 * kg + (li >> 2);
   const int seg = (li & 1) * 8, hbit = (li >> 1) & 1;
-  // dy: pixel index in its image = row * 32 + kpx (+ 4): bits 1 and 3 do not depend on the row or the + 4
-  const int yphi = wg64_phi(kpx);
+  // dy: a k-step is 32 consecutive pixels of the [TH][TW] image; the lane's column is kpx % TW (+ 4): bits 1 and 3 of it
+  // do not depend on the k-step or the + 4
+  const int yphi = wg64_phi(kpx % G::TW);
   int aoff[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
-    aoff[mt] = G::X_BYTES + ((4 * kgp) * G::TW + kpx) * 128 + (((2 * (wco * 2 + mt) + hbit) ^ (2 * yphi)) * 16) + seg;
+    aoff[mt] = G::X_BYTES + (kgp * 128 + kpx) * 128 + (((2 * (wco * 2 + mt) + hbit) ^ (2 * yphi)) * 16) + seg;
 
-  // x: the swizzle is a function of the halo COLUMN (a halo row is 34 * 128 B = 17 times all 64 banks: rows do not move
-  // banks), so a tap's row is an immediate offset and the lane part is one of 3 (tap column) x 2 (tile) x 2 (read) values
+  // x: the swizzle is a function of the halo COLUMN (a halo row is 34 (18) * 128 B = 17 (9) times all 64 banks: rows do
+  // not move banks), so a tap's row is an immediate offset and the lane part is one of 3 (tap column) x 2 (tile) x 2 (read)
+  // values; at TW = 16 the lane's pixel sits in row kpx / 16 of the k-step's two rows
   int boff[3][2][2];
 #pragma unroll
   for (int sx = 0; sx < 3; ++sx)
@@ -1330,8 +1336,8 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad64_kernel(WgradArgs a) {
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int hx = kpx + sx + 4 * h;
-        boff[sx][nt][h] = hx * 128 + (((2 * (wci * 2 + nt) + hbit) ^ (2 * wg64_phi(hx))) * 16) + seg;
+        const int hx = kpx % G::TW + sx + 4 * h;
+        boff[sx][nt][h] = ((kpx / G::TW) * G::IW + hx) * 128 + (((2 * (wci * 2 + nt) + hbit) ^ (2 * wg64_phi(hx))) * 16) + seg;
       }
   auto tr2 = [&](const unsigned char* p0, const unsigned char* p1) {
     const ffa_s16x4 v0 = lds_read_tr16(p0);
@@ -1350,23 +1356,21 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad64_kernel(WgradArgs a) {
     int slot = 0;
     for (int it = 0; it < ntl; ++it) {
       wgthin_wait_and_meet<0>();  // this tile's fill has landed (nothing younger is in flight); the other slot is free
-      // the two waves of a SIMD are the two k groups of one (co, ci) sub-tile: group 0 issues the next tile's fill now,
-      // group 1 after half of its products, so that one of them is always feeding the matrix pipe
       const bool more = it + 1 < ntl;
       if (more) issue_tile(split + (it + 1) * a.nsplit, slot ^ 1);
       const unsigned char* sS = smem + slot * G::SLOT;
-      // the k group's four rows = four k-steps of 32 pixels.  Tap (r, s) of row rr reads halo row rr + r at column shift s:
-      // each of the 6 x 3 (halo row, shift) fragments is read ONCE and multiplied with the dy fragments of the up to
-      // three rows it serves (half the LDS reads of a per-tap walk, which were the kernel's bound: 160 reads of 512 B per
-      // wave and tile = 1.1 x the matrix pipe's time)
-      ffa_u32x4 af[4][2];  // row hr is read when halo row hr starts and dies after halo row hr + 2: two or three rows live
-      const unsigned char* sRow = sS + (4 * kgp) * (G::IW * 128);
+      // the k group's four k-steps of 32 pixels (RS = 1 or 2 image rows each).  Tap (r, s) of k-step j reads the halo rows
+      // from RS * j + r on, at column shift s: each (start row, shift) fragment is read ONCE and multiplied with the dy
+      // fragments of every k-step it serves -- up to three at RS = 1: 88 instead of 160 LDS reads per wave and tile, which
+      // were the kernel's bound (1.1 x the matrix pipe's time); two at RS = 2 (start rows 0 .. 8, the odd ones serve r = 1)
+      ffa_u32x4 af[4][2];  // k-step j is read when its first start row comes up and dies 2 start rows later
+      const unsigned char* sRow = sS + (G::RS * 4 * kgp) * (G::IW * 128);
 #pragma unroll
-      for (int hr = 0; hr < 6; ++hr) {
-        if (hr < 4) {
+      for (int hr = 0; hr < G::RS * 3 + 3; ++hr) {
+        if (hr % G::RS == 0 && hr / G::RS < 4) {
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
-            af[hr][mt] = tr2(sS + aoff[mt] + hr * G::TW * 128, sS + aoff[mt] + hr * G::TW * 128 + 4 * 128);
+            af[hr / G::RS][mt] = tr2(sS + aoff[mt] + (hr / G::RS) * 32 * 128, sS + aoff[mt] + (hr / G::RS) * 32 * 128 + 4 * 128);
         }
 #pragma unroll
         for (int sx = 0; sx < 3; ++sx) {
@@ -1375,8 +1379,8 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad64_kernel(WgradArgs a) {
             const ffa_u32x4 bf = tr2(sRow + hr * (G::IW * 128) + boff[sx][nt][0], sRow + hr * (G::IW * 128) + boff[sx][nt][1]);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-              const int rr = hr - r;
-              if (rr < 0 || rr > 3) continue;
+              if (hr - r < 0 || (hr - r) % G::RS != 0 || (hr - r) / G::RS > 3) continue;
+              const int rr = (hr - r) / G::RS;
 #pragma unroll
               for (int mt = 0; mt < 2; ++mt)
                 acc[mt][nt][r * 3 + sx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -1610,16 +1614,22 @@ static int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int kh, int kw, 
         return ffa_check_launch("conv_wgrad");
       }
       {
-        // conv3x3_wgrad64_kernel: whole 64-channel blocks, wide maps (FFA_WGRAD64=0: conv_wgrad_kernel)
+        // conv3x3_wgrad64_kernel: whole 64-channel blocks, 8 x 32 or 16 x 16 tiles (FFA_WGRAD64=0: conv_wgrad_kernel)
         const char* e64 = getenv("FFA_WGRAD64");
-        if (!(e64 && e64[0] == '0') && p.wco == 2 && p.wci == 2 && p.wk == 2 && wide && p.th == 8 && a.C1 % 64 == 0 &&
+        const int ih = wide ? 10 : 18, iw = wide ? 34 : 18;
+        if (!(e64 && e64[0] == '0') && p.wco == 2 && p.wci == 2 && p.wk == 2 && p.th == (wide ? 8 : 16) && a.C1 % 64 == 0 &&
             (a.C1 == 0 || (a.Hi % 2 == 0 && a.Wi % 2 == 0)) && a.pad == 1 && a.Co % 64 == 0 && a.Ci % 64 == 0 &&
-            (10LL * a.Wi + 34) * 2 * (a.Ci > a.Co ? a.Ci : a.Co) < (1LL << 24)) {
+            ((long long)ih * a.Wi + iw) * 2 * (a.Ci > a.Co ? a.Ci : a.Co) < (1LL << 23)) {
           hipEvent_t ts, te;
-          if (ffa_ktime_next(FFA_KT_WGRAD64, &ts, &te))
-            hipExtLaunchKernelGGL(conv3x3_wgrad64_kernel, dim3(a.ncob * a.ncib, a.nsplit), dim3(512), 0, stream, ts, te, 0, a);
-          else
-            hipLaunchKernelGGL(conv3x3_wgrad64_kernel, dim3(a.ncob * a.ncib, a.nsplit), dim3(512), 0, stream, a);
+          const dim3 grid(a.ncob * a.ncib, a.nsplit);
+          const bool timed = ffa_ktime_next(FFA_KT_WGRAD64, &ts, &te);
+          if (wide) {
+            if (timed) hipExtLaunchKernelGGL(conv3x3_wgrad64_kernel<32>, grid, dim3(512), 0, stream, ts, te, 0, a);
+            else hipLaunchKernelGGL(conv3x3_wgrad64_kernel<32>, grid, dim3(512), 0, stream, a);
+          } else {
+            if (timed) hipExtLaunchKernelGGL(conv3x3_wgrad64_kernel<16>, grid, dim3(512), 0, stream, ts, te, 0, a);
+            else hipLaunchKernelGGL(conv3x3_wgrad64_kernel<16>, grid, dim3(512), 0, stream, a);
+          }
           return ffa_check_launch("conv3x3_wgrad64");
         }
       }

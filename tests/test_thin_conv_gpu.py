@@ -160,7 +160,9 @@ def test_thin_wgrad_matches_torch_and_the_general_kernel(cuda, monkeypatch, cin,
     assert torch.equal(got, again)  # fixed summation order
 
 
-WG64_CASES = [(64, 64, 3, 32, 64), (64, 128, 2, 40, 48), (128, 64, 2, 17, 33), (128, 128, 5, 64, 64), (256, 64, 1, 8, 96)]
+WG64_CASES = [(64, 64, 3, 32, 64), (64, 128, 2, 40, 48), (128, 64, 2, 17, 33), (128, 128, 5, 64, 64), (256, 64, 1, 8, 96),
+              # maps narrower than 32: the 16 x 16-tile instantiation (two image rows per 32-pixel k-step)
+              (256, 256, 3, 16, 16), (64, 128, 2, 12, 20), (128, 128, 4, 8, 8), (512, 64, 2, 33, 16), (64, 64, 1, 5, 31)]
 
 
 @pytest.mark.parametrize("cin,cout,B,H,W", WG64_CASES, ids=[f"c{c[0]}-{c[1]}_b{c[2]}_{c[3]}x{c[4]}" for c in WG64_CASES])
