@@ -926,13 +926,22 @@ __global__ void __launch_bounds__(64 * WCO * WPX, OCC) conv3x3_ring16_kernel(Rin
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
           }
-          ffa_store8<T>(out + pix + c0, v);
+          // rounded once: the stored words are also what the statistics are taken from (the values BatchNorm will read)
+          ffa_u32x4 u;
+          u.x = ffa_pack_bf16x2(v[0], v[1]);
+          u.y = ffa_pack_bf16x2(v[2], v[3]);
+          u.z = ffa_pack_bf16x2(v[4], v[5]);
+          u.w = ffa_pack_bf16x2(v[6], v[7]);
+          *reinterpret_cast<ffa_u32x4*>(out + pix + c0) = u;
           if (want_stats) {
+            const float rr[8] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                 __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u),
+                                 __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
+                                 __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-              const float rr = ffa_bf16_bits_to_f32(ffa_f32_to_bf16_bits(v[i]));
-              st[h * 8 + i] += rr;
-              st[16 + h * 8 + i] = __builtin_fmaf(rr, rr, st[16 + h * 8 + i]);  // explicit: all conv kernels round alike
+              st[h * 8 + i] += rr[i];
+              st[16 + h * 8 + i] = __builtin_fmaf(rr[i], rr[i], st[16 + h * 8 + i]);  // explicit: all conv kernels round alike
             }
           }
         }
