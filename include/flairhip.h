@@ -47,12 +47,14 @@ const char* ffa_target_arch(void);
 int ffa_conv_block_co(int kh, int kw, int stride, int cout);
 /* Operand layout + block height of a layer: the `bco` value for ffa_pack_conv_weight / ffa_pack_desc_fill /
  * ffa_conv2d / ffa_conv2d_stats / ffa_conv_stat_rows.  Bits 0..11 = rows per block (pad the row count to a multiple
- * of it); FFA_BCO_RING set = the operand is packed for the LDS-DMA ring kernel (conv3x3_ring_kernel: 3x3 stride 1
- * pad 1, >= 64 output channels, whole 64-byte groups of input channels).  Pass allow_ring = 0 for operands that feed
- * ffa_conv2d_upcat / ffa_conv2d_dgrad_upcat / ffa_conv2d_bnbwd or a dil = 2 call.  The ring layout is opt-in:
- * FFA_RING=1 in the environment (measured equal to / slightly behind the conv_igemm kernels). */
+ * of it); FFA_BCO_RING set = the operand is packed for the LDS-DMA ring kernels (bf16: conv3x3_ring16_kernel, the default
+ * for 3x3 stride 1 pad 1 layers with >= 64 output channels and whole 64-byte groups of input channels -- FFA_RING=0 in the
+ * environment restores the conv_igemm kernels; f32: conv3x3_ring_kernel, FFA_RING=1); bit 13 (0x2000) = the
+ * register-resident operand of the thin layers (ffa_thin_*; FFA_THIN=0 disables).  `allow`: bit 0 admits the ring
+ * layout, bit 1 the thin one; pass 0 for operands that feed ffa_conv2d_bnbwd or a dil = 2 call. */
 #define FFA_BCO_RING 0x1000
-int ffa_conv_plan(int dtype, int kh, int kw, int stride, int cout, int ci_pitch, int allow_ring);
+#define FFA_BCO_THIN 0x2000
+int ffa_conv_plan(int dtype, int kh, int kw, int stride, int cout, int ci_pitch, int allow);
 /* The ring kernel called directly: out = relu?(conv3x3(in', w) + bias + residual) with in' = in, or -- when
  * pro_scale / pro_shift are given -- in' = relu(in * pro_scale[c] + pro_shift[c]) evaluated while the input tile is
  * staged (the training-mode BatchNorm + ReLU of the producing layer folded into this convolution's loader: replaces
