@@ -1673,6 +1673,41 @@ extern "C" int ffa_pack_desc_fill(void* host_desc, const float* w_oihw, const fl
   return FFA_OK;
 }
 
+// The same descriptor for the column block W[:, col0 : col0 + ncols] of a weight with I_total input channels (one
+// modality's share of a FusionHandler 1x1 convolution, flair_hub/models/flair_model.py:470-475): the source strides
+// stay those of the whole tensor, so the slices of every stage ride in the batched pack instead of one copy + one
+// pack launch each.
+extern "C" int ffa_pack_desc_fill_cols(void* host_desc, const float* w_oihw, const float* scale, void* dst, int O,
+                                       int I_total, int col0, int ncols, int kh, int kw, int transpose, int co_rows,
+                                       int ci_pitch, int bco, int rg, int dtype) {
+  FFA_REQUIRE(host_desc && w_oihw && dst, "pack_desc_fill_cols: null pointer");
+  FFA_REQUIRE(col0 >= 0 && ncols > 0 && col0 + ncols <= I_total, "pack_desc_fill_cols: column block outside the tensor");
+  FFA_REQUIRE(bco > 0 && co_rows % bco == 0 && rg > 0 && kh % rg == 0 && ci_pitch % 16 == 0,
+              "pack_desc_fill_cols: bad geometry");
+  PackArgs p;
+  memset(&p, 0, sizeof(p));
+  p.src = w_oihw + (long long)col0 * kh * kw;
+  p.dst = dst;
+  p.scale = scale;
+  if (!transpose) {
+    p.rows = O; p.chs = ncols;
+    p.s_row = (long long)I_total * kh * kw;
+    p.s_ch = (long long)kh * kw;
+    p.flip = 0;
+  } else {
+    p.rows = ncols; p.chs = O;
+    p.s_row = (long long)kh * kw;
+    p.s_ch = (long long)I_total * kh * kw;
+    p.flip = 1;
+  }
+  FFA_REQUIRE(p.rows <= co_rows && p.chs <= ci_pitch, "pack_desc_fill_cols: padded dims smaller than the block");
+  p.kh = kh; p.kw = kw; p.rg = rg; p.bco = bco;
+  p.nchunks = ci_pitch / ((dtype == FFA_BF16) ? 16 : 8);
+  p.ncb = co_rows / bco;
+  memcpy(host_desc, &p, sizeof(p));
+  return FFA_OK;
+}
+
 extern "C" int ffa_pack_conv_weights_batched(int dtype, const void* descs_device, int n, hipStream_t stream) {
   FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "pack_batched: bad dtype");
   FFA_REQUIRE(descs_device && n > 0 && n <= 65535, "pack_batched: bad descriptor table");

@@ -50,6 +50,7 @@ SIGNATURES = {
     "ffa_pack_conv_weight": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "ffa_pack_desc_bytes": (_i, []),
     "ffa_pack_desc_fill": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "ffa_pack_desc_fill_cols": (_i, [_p, _p, _p, _p] + [_i] * 12),
     "ffa_pack_conv_weights_batched": (_i, [_i, _p, _i, _p]),
     "ffa_conv2d": (_i, [_i, _p, _p, _p, _p, _p] + [_i] * 15 + [_p]),
     "ffa_conv_stat_rows": (_ll, [_i, _i, _i, _i, _i]),

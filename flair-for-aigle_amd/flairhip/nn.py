@@ -139,22 +139,32 @@ class PackPlan:
                         continue
                     entries.append((c.weight.detach(), hit[1], transpose))
                     sig.append((c.weight.data_ptr(), hit[1].data.data_ptr()))
-                    slots.append((c, transpose, tag))
+                    slots.append((c, (dtype, transpose, tag)))
+            # column blocks of fusion 1x1 weights (FusionHandler.conv_f: one operand per modality and direction)
+            for key, hit in c._cache.items():
+                if isinstance(key, tuple) and key and key[0] == "fusion_slice" and key[3] == dtype:
+                    pw = hit[1]
+                    if pw.bco & (ops._l.BCO_RING | ops._l.BCO_THIN):
+                        continue
+                    entries.append((c.weight.detach(), pw, key[5], (key[1], key[2])))
+                    sig.append((c.weight.data_ptr(), pw.data.data_ptr()))
+                    slots.append((c, key))
         if not entries:
             return
-        versions = [c.weight._version for c, _, _ in slots]
+        versions = [c.weight._version for c, _ in slots]
         if self.batch is None or sig != self.sig:
             if not all(e[0].is_contiguous() for e in entries):
                 return
             self.batch, self.sig, self.versions = ops.PackBatch(entries, dtype), sig, None
-        stale = [i for i, (c, tr, tag) in enumerate(slots)
-                 if c._cache[(dtype, tr, tag)][0][0] != versions[i] or c._cache[(dtype, tr, tag)][0][3] != _STATE_EPOCH]
+        # cache stamps: (version, data_ptr, scale version, epoch) for whole weights, (version, data_ptr, epoch) for blocks
+        stale = [i for i, (c, key) in enumerate(slots)
+                 if c._cache[key][0][0] != versions[i] or c._cache[key][0][-1] != _STATE_EPOCH]
         if not stale:
             return
         self.batch.run()
-        for (c, tr, tag), v in zip(slots, versions):
-            key = (dtype, tr, tag)
-            c._cache[key] = ((v, c.weight.data_ptr(), None, _STATE_EPOCH), c._cache[key][1])
+        for (c, key), v in zip(slots, versions):
+            stamp = (v, c.weight.data_ptr(), _STATE_EPOCH) if key[0] == "fusion_slice" else (v, c.weight.data_ptr(), None, _STATE_EPOCH)
+            c._cache[key] = (stamp, c._cache[key][1])
 
 
 class HipBatchNorm2d(nn.Module):

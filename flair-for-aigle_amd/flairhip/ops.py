@@ -121,7 +121,7 @@ class PackBatch:
     """Descriptor tables for ffa_pack_conv_weights_batched / ffa_ring_pack_batched: re-packs many conv operands in one
     launch per layout.
 
-    entries: (master weight OIHW f32, PackedWeight it feeds, transpose flag).  The tables hold raw device
+    entries: (master weight OIHW f32, PackedWeight it feeds, transpose flag[, (first column, columns)]).  The tables hold raw device
     pointers, so they must be rebuilt when a parameter or a packed buffer is re-allocated."""
 
     def __init__(self, entries, dtype: torch.dtype):
@@ -139,11 +139,18 @@ class PackBatch:
             nb = lib.ffa_pack_desc_bytes()
             host = C.create_string_buffer(nb * len(plain))
             base = C.addressof(host)
-            for i, (w, pw, transpose) in enumerate(plain):
+            for i, e in enumerate(plain):
+                w, pw, transpose = e[:3]
                 O, I, kh, kw = w.shape
-                _l.check(lib.ffa_pack_desc_fill(base + i * nb, w.data_ptr(), None, pw.data.data_ptr(), O, I, kh, kw,
-                                                1 if transpose else 0, pw.rows, pw.ci_pitch, pw.bco,
-                                                lib.ffa_conv_row_group(kh), self.dtype_id), "pack_desc_fill")
+                if len(e) > 3:  # column block W[:, off : off + c] of a fusion 1x1 weight
+                    off, c = e[3]
+                    _l.check(lib.ffa_pack_desc_fill_cols(base + i * nb, w.data_ptr(), None, pw.data.data_ptr(), O, I, off, c,
+                                                         kh, kw, 1 if transpose else 0, pw.rows, pw.ci_pitch, pw.bco,
+                                                         lib.ffa_conv_row_group(kh), self.dtype_id), "pack_desc_fill_cols")
+                else:
+                    _l.check(lib.ffa_pack_desc_fill(base + i * nb, w.data_ptr(), None, pw.data.data_ptr(), O, I, kh, kw,
+                                                    1 if transpose else 0, pw.rows, pw.ci_pitch, pw.bco,
+                                                    lib.ffa_conv_row_group(kh), self.dtype_id), "pack_desc_fill")
                 self.keep.append((w, pw))
             self.table = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
         if ring:

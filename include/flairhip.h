@@ -103,6 +103,11 @@ int ffa_pack_conv_weight(int dtype, const float* w_oihw, const float* scale, voi
 int ffa_pack_desc_bytes(void);
 int ffa_pack_desc_fill(void* host_desc, const float* w_oihw, const float* scale, void* dst, int O, int I, int kh,
                        int kw, int transpose, int co_rows, int ci_pitch, int bco, int rg, int dtype);
+/* descriptor for the column block W[:, col0 : col0 + ncols] of a weight with I_total input channels (one modality's share
+ * of a FusionHandler 1x1 convolution, flair_hub/models/flair_model.py:470-475,533-541) */
+int ffa_pack_desc_fill_cols(void* host_desc, const float* w_oihw, const float* scale, void* dst, int O, int I_total,
+                            int col0, int ncols, int kh, int kw, int transpose, int co_rows, int ci_pitch, int bco, int rg,
+                            int dtype);
 int ffa_pack_conv_weights_batched(int dtype, const void* descs_device, int n, ffa_stream_t stream);
 /* out = relu?( conv(in, w) + bias + residual ).  dil=2 reads `in` through a virtual zero insertion
  * (dgrad of a stride-2 layer, stride must then be 1). */
