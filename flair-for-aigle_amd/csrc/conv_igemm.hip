@@ -1199,6 +1199,11 @@ extern "C" int ffa_ring_pack(int dtype, const float* w_oihw, const float* scale,
                              int co_rows, int ci_pitch, hipStream_t stream);
 
 // thin kernel entry points (conv3x3_thin.hip)
+extern "C" int ffa_stem_eligible(int dtype, int kh, int kw, int stride, int cout, int ci_pitch);
+extern "C" long long ffa_stem_stat_rows(int B, int Ho, int Wo);
+extern "C" int ffa_stem_pack(const float* w_oihw, const float* scale, void* dst, int O, int I, hipStream_t stream);
+extern "C" int ffa_stem_conv7x7(const void* in, const void* w_stem, const float* bias, void* out, float* stat_partials, int B,
+                                int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int relu, hipStream_t stream);
 extern "C" int ffa_thin_eligible(int dtype, int kh, int kw, int stride, int rows_real, int ci_pitch);
 extern "C" long long ffa_thin_stat_rows(int B, int H, int W, int ci_pitch);
 extern "C" int ffa_thin_conv3x3(const void* in, const void* w_thin, const float* bias, const void* residual, void* out,
@@ -1226,6 +1231,12 @@ extern "C" int ffa_thin_conv3x3_pro(const void* in, const void* w_thin, const fl
 extern "C" int ffa_conv_plan(int dtype, int kh, int kw, int stride, int cout, int ci_pitch, int allow_ring) {
   const int bco = ffa_conv_block_co(kh, kw, stride, cout);
   if (bco < 0) return bco;
+  {
+    // the ResNet stem (bit 2 of `allow`; FFA_STEM=0 keeps conv_igemm_kernel<7, 7, 2>)
+    const char* t = getenv("FFA_STEM");
+    if ((allow_ring & 4) && !(t && t[0] == '0') && ffa_stem_eligible(dtype, kh, kw, stride, cout, ci_pitch))
+      return 64 | FFA_BCO_STEM;
+  }
   {
     const char* t = getenv("FFA_THIN");
     if ((allow_ring & 2) && !(t && t[0] == '0') && ffa_thin_eligible(dtype, kh, kw, stride, cout, ci_pitch))
@@ -1255,6 +1266,12 @@ static int conv2d_impl(int dtype, const void* in, const void* w_packed, const fl
   FFA_REQUIRE(dil == 1 || stride == 1, "conv: zero-insertion input needs stride 1");
   FFA_REQUIRE((long long)B * Hi * Wi * Ci * (dtype == FFA_BF16 ? 2 : 4) < (1LL << 31),
               "conv: input tensor must be smaller than 2 GiB (32-bit piece offsets)");
+  if (bco & FFA_BCO_STEM) {
+    FFA_REQUIRE(dtype == FFA_BF16 && kh == 7 && kw == 7 && stride == 2 && pad == 3 && dil == 1 && c1_out == 0 && bnx == nullptr &&
+                    residual == nullptr,
+                "conv: a stem-layout operand serves the bf16 7x7 stride-2 pad-3 convolution only (no residual input)");
+    return ffa_stem_conv7x7(in, w_packed, bias, out, stat_partials, B, Hi, Wi, Ci, Ho, Wo, Co, relu, stream);
+  }
   if (bco & FFA_BCO_THIN) {
     FFA_REQUIRE(dtype == FFA_BF16 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && dil == 1 && Hi == Ho && Wi == Wo &&
                     bnx == nullptr,
@@ -1359,6 +1376,7 @@ static long long conv_stat_rows_igemm(int B, int Ho, int Wo) {
 // co_rows / bco: the operand the convolution will run with (ffa_conv_plan); the row count is the number of pixel
 // tiles of the kernel that serves it
 extern "C" long long ffa_conv_stat_rows(int B, int Ho, int Wo, int co_rows, int bco) {
+  if (bco & FFA_BCO_STEM) return ffa_stem_stat_rows(B, Ho, Wo);
   if (bco & FFA_BCO_THIN) return ffa_thin_stat_rows(B, Ho, Wo, (bco & FFA_BCO_THIN32) ? 32 : 16);
   if (bco & FFA_BCO_RING) return ffa_ring_stat_rows(B, Ho, Wo, co_rows);
   return conv_stat_rows_igemm(B, Ho, Wo);
@@ -1371,7 +1389,7 @@ extern "C" int ffa_conv_is_persistent(int dtype, int B, int Ho, int Wo, int Ci, 
   if (!(kh == 3 && kw == 3 && stride == 1) || bco <= 0 || co_rows % bco != 0) return 0;
   const int nchunks = Ci * (dtype == FFA_BF16 ? 2 : 4) / 32;
   if (nchunks % 2 != 0) return 0;  // HK = 1 instantiations have no pipelined path
-  if (bco & (FFA_BCO_RING | FFA_BCO_THIN)) return 0;
+  if (bco & (FFA_BCO_RING | FFA_BCO_THIN | FFA_BCO_STEM)) return 0;
   const int npt = (int)conv_stat_rows_igemm(B, Ho, Wo);
   return conv_persist_grid(dil, 0, nullptr, ffa_cdiv(npt, 8) * 8 * (co_rows / bco)) > 0 ? 1 : 0;
 }
@@ -1543,6 +1561,10 @@ extern "C" int ffa_pack_conv_weight(int dtype, const float* w_oihw, const float*
                                     hipStream_t stream) {
   FFA_REQUIRE(dtype == FFA_BF16 || dtype == FFA_F32, "pack: bad dtype");
   FFA_REQUIRE(w_oihw && dst, "pack: null pointer");
+  if (bco & FFA_BCO_STEM) {
+    FFA_REQUIRE(kh == 7 && kw == 7 && dtype == FFA_BF16 && !transpose, "pack: the stem layout is for the bf16 7x7 forward operand");
+    return ffa_stem_pack(w_oihw, scale, dst, O, I, stream);
+  }
   if (bco & FFA_BCO_THIN) {
     FFA_REQUIRE(kh == 3 && kw == 3 && dtype == FFA_BF16, "pack: the thin layout is for bf16 3x3 kernels");
     return ffa_thin_pack(w_oihw, scale, dst, O, I, transpose, co_rows, ci_pitch, stream);

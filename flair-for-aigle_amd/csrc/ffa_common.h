@@ -22,6 +22,7 @@
 #define FFA_BCO_RING 0x1000  // `bco` flag: operand packed for conv3x3_ring_kernel (ffa_conv_plan)
 #define FFA_BCO_THIN 0x2000  // `bco` flag: operand packed for conv3x3_thin_kernel (<= 32 input channels, <= 32 rows)
 #define FFA_BCO_THIN32 0x4000  // with FFA_BCO_THIN: the operand multiplies 32-channel pixels (8-row tiles; else 16 ch, 16-row tiles)
+#define FFA_BCO_STEM 0x8000   // `bco` flag: operand packed for conv7x7_stem_kernel (bf16 7x7 stride 2, <= 8 real input channels, 64 rows)
 
 void ffa_set_error(const char* fmt, ...);
 int ffa_check_launch(const char* what);

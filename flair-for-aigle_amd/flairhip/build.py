@@ -16,7 +16,7 @@ CSRC = os.path.normpath(os.path.join(HERE, "..", "csrc"))
 OUT = os.path.join(HERE, "libflairhip.so")
 OBJ = os.path.join(CSRC, "build")
 
-HIP_SOURCES = ["ffa_runtime.hip", "conv_igemm.hip", "conv3x3_ring.hip", "conv3x3_thin.hip", "conv_wgrad.hip", "norm_pool.hip", "resample_loss.hip", "temporal.hip", "transformer.hip", "gemm.hip", "optim.hip"]
+HIP_SOURCES = ["ffa_runtime.hip", "conv_igemm.hip", "conv3x3_ring.hip", "conv3x3_thin.hip", "conv7x7_stem.hip", "conv_wgrad.hip", "norm_pool.hip", "resample_loss.hip", "temporal.hip", "transformer.hip", "gemm.hip", "optim.hip"]
 CXX_SOURCES = ["tile_grid.cpp", "tiff_codec.cpp"]
 HEADERS = ["ffa_common.h", "ffa_common_host.h", os.path.join("..", "..", "include", "flairhip.h")]
 ARCH = "gfx950"

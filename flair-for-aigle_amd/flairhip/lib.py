@@ -17,6 +17,7 @@ BF16 = 0
 F32 = 1
 BCO_RING = 0x1000  # FFA_BCO_RING
 BCO_THIN = 0x2000  # FFA_BCO_THIN
+BCO_STEM = 0x8000  # FFA_BCO_STEM
 ERR_UNSUPPORTED = -2  # FFA_ERR_UNSUPPORTED: no kernel for the requested shape (callers may fall back to another op)
 
 
@@ -61,6 +62,11 @@ SIGNATURES = {
     "ffa_conv2d_pro": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 9 + [_p]),
     "ffa_conv_wgrad_pro": (_i, [_i, _p, _p, _p, _p, _p] + [_i] * 11 + [_p, _ll, _p]),
     "ffa_thin_eligible": (_i, [_i] * 6),
+    "ffa_stem_eligible": (_i, [_i] * 6),
+    "ffa_stem_pack_bytes": (_ll, []),
+    "ffa_stem_stat_rows": (_ll, [_i, _i, _i]),
+    "ffa_stem_pack": (_i, [_p, _p, _p, _i, _i, _p]),
+    "ffa_stem_conv7x7": (_i, [_p, _p, _p, _p, _p] + [_i] * 8 + [_p]),
     "ffa_thin_stat_rows": (_ll, [_i, _i, _i, _i]),
     "ffa_thin_conv3x3": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 9 + [_p]),
     "ffa_thin_conv3x3_pro": (_i, [_p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 9 + [_p]),

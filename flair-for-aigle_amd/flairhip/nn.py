@@ -81,7 +81,7 @@ class HipConv2d(nn.Module):
             w = w.contiguous()
         pitch = self.out_pitch if transpose else self.in_pitch
         pw = ops.pack_conv_weight(w, dtype, self.stride, pitch, transpose=transpose, scale=scale, allow_ring=ring,
-                                  allow_thin=thin)
+                                  allow_thin=thin, allow_stem=(self.padding == 3))
         self._cache[key] = (ver, pw)
         return pw
 
@@ -671,7 +671,8 @@ def _eval_folded(conv: HipConv2d, bn: HipBatchNorm2d, dtype: torch.dtype, ring: 
                                           bn.eps)
         w = conv.weight.detach()
         pw = ops.pack_conv_weight(w if w.is_contiguous() else w.contiguous(), dtype, conv.stride, conv.in_pitch,
-                                  scale=scale, allow_ring=ring and conv.padding == 1, allow_thin=conv.padding == 1)
+                                  scale=scale, allow_ring=ring and conv.padding == 1, allow_thin=conv.padding == 1,
+                                  allow_stem=conv.padding == 3)
         hit = (ver, pw, shift)
         conv._cache[ck] = hit
     return hit[1], hit[2]

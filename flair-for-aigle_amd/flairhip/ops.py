@@ -86,12 +86,13 @@ class PackedWeight:
 
 def pack_conv_weight(w_oihw: torch.Tensor, dtype: torch.dtype, stride: int, ci_pitch: int,
                      transpose: bool = False, scale: Optional[torch.Tensor] = None,
-                     allow_ring: bool = True, allow_thin: bool = True) -> PackedWeight:
+                     allow_ring: bool = True, allow_thin: bool = True, allow_stem: bool = True) -> PackedWeight:
     """OIHW f32 master weight -> MFMA operand for ffa_conv2d (forward, or dgrad when transpose=True).
     allow_ring=False keeps the operand in the conv_igemm layout (needed by the two-source / split-epilogue /
     zero-insertion calls); otherwise ffa_conv_plan picks the LDS-DMA ring layout where it applies.  allow_thin:
     bf16 layers with at most 32 stored input channels and 32 rows may get the register-resident layout of
-    conv3x3_thin_kernel (plain, statistics, skip-less two-source and skip-less pooled-split calls)."""
+    conv3x3_thin_kernel (plain, statistics, skip-less two-source and skip-less pooled-split calls).  allow_stem: the bf16
+    forward operand of a 7x7 stride-2 PAD-3 convolution over <= 8 real input channels gets conv7x7_stem_kernel's layout."""
     lib = _l.load()
     if w_oihw.dtype != torch.float32 or not w_oihw.is_contiguous():
         raise ValueError("pack_conv_weight: master weight must be contiguous f32 OIHW")
@@ -102,7 +103,10 @@ def pack_conv_weight(w_oihw: torch.Tensor, dtype: torch.dtype, stride: int, ci_p
     # the dgrad operand of a stride-2 layer is read through the zero insertion (dil = 2): conv_igemm only
     ring_ok = allow_ring and not (transpose and stride != 1)
     thin_ok = allow_thin and not (transpose and stride != 1)
-    bco = lib.ffa_conv_plan(did, kh, kw, use_stride, rows_real, ci_pitch, (1 if ring_ok else 0) | (2 if thin_ok else 0))
+    # the stem kernel stages the first 8 channels of a pixel only: forward operand of a <= 8-channel input
+    stem_ok = allow_stem and not transpose and I <= 8  # (the caller vouches for pad = 3)
+    bco = lib.ffa_conv_plan(did, kh, kw, use_stride, rows_real, ci_pitch,
+                            (1 if ring_ok else 0) | (2 if thin_ok else 0) | (4 if stem_ok else 0))
     if bco <= 0:
         raise _l.FlairHipError(f"no conv kernel for {kh}x{kw} stride {use_stride}")
     blk = bco & 0xFFF
@@ -111,6 +115,8 @@ def pack_conv_weight(w_oihw: torch.Tensor, dtype: torch.dtype, stride: int, ci_p
     nbytes = lib.ffa_pack_conv_weight_bytes(did, rows, ci_pitch, kh, kw)
     if bco & _l.BCO_THIN:
         nbytes = lib.ffa_thin_pack_bytes(rows, ci_pitch)
+    if bco & _l.BCO_STEM:
+        nbytes = lib.ffa_stem_pack_bytes()
     dst = torch.empty(nbytes // (2 if dtype == torch.bfloat16 else 4), dtype=dtype, device=w_oihw.device)
     _l.check(lib.ffa_pack_conv_weight(did, w_oihw.data_ptr(), _ptr(scale), dst.data_ptr(), O, I, kh, kw,
                                       1 if transpose else 0, rows, ci_pitch, bco, rg, _stream()), "pack_conv_weight")
@@ -128,7 +134,8 @@ class PackBatch:
         lib = _l.load()
         self.dtype_id = _dtype_id(dtype)
         self.keep = []
-        plain = [e for e in entries if not (e[1].bco & (_l.BCO_RING | _l.BCO_THIN))]
+        plain = [e for e in entries if not (e[1].bco & (_l.BCO_RING | _l.BCO_THIN | _l.BCO_STEM))]
+        self.stem = [e for e in entries if e[1].bco & _l.BCO_STEM]  # one operand per encoder: packed by its own small launch
         ring = [e for e in entries if e[1].bco & _l.BCO_RING]
         thin = [e for e in entries if e[1].bco & _l.BCO_THIN]
         self.n, self.table = len(plain), None
@@ -185,6 +192,8 @@ class PackBatch:
                      "ring_pack_batched")
         if self.table_thin is not None:
             _l.check(lib.ffa_thin_pack_batched(self.table_thin.data_ptr(), self.n_thin, _stream()), "thin_pack_batched")
+        for w, pw, transpose in self.stem:
+            _l.check(lib.ffa_stem_pack(w.data_ptr(), None, pw.data.data_ptr(), w.shape[0], w.shape[1], _stream()), "stem_pack")
 
 
 def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:

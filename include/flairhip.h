@@ -51,7 +51,7 @@ int ffa_conv_block_co(int kh, int kw, int stride, int cout);
  * for 3x3 stride 1 pad 1 layers with >= 64 output channels and whole 64-byte groups of input channels -- FFA_RING=0 in the
  * environment restores the conv_igemm kernels; f32: conv3x3_ring_kernel, FFA_RING=1); bit 13 (0x2000) = the
  * register-resident operand of the thin layers (ffa_thin_*; FFA_THIN=0 disables).  `allow`: bit 0 admits the ring
- * layout, bit 1 the thin one; pass 0 for operands that feed ffa_conv2d_bnbwd or a dil = 2 call. */
+ * layout, bit 1 the thin one, bit 2 the stem one (0x8000); pass 0 for operands that feed ffa_conv2d_bnbwd or a dil = 2 call. */
 #define FFA_BCO_RING 0x1000
 #define FFA_BCO_THIN 0x2000
 int ffa_conv_plan(int dtype, int kh, int kw, int stride, int cout, int ci_pitch, int allow);
@@ -92,6 +92,17 @@ int ffa_thin_pack_desc_bytes(void);
 int ffa_thin_pack_desc_fill(void* host_desc, const float* w_oihw, const float* scale, void* dst, int O, int I,
                             int transpose, int co_rows, int ci_pitch);
 int ffa_thin_pack_batched(const void* descs_device, int n, ffa_stream_t stream);
+/* The ResNet stem (bf16 7x7 stride-2 pad-3 convolution of a <= 8-channel tile stored at pitch 16 into 64 channels;
+ * csrc/conv7x7_stem.hip; torchvision's conv1 as smp's ResNetEncoder keeps it): four adjacent taps x 8 channels per
+ * K = 32 MFMA step, only the first 16 bytes of every input pixel are staged.  ffa_conv2d / ffa_conv2d_stats dispatch here
+ * when the operand was packed for it (ffa_conv_plan with bit 2 of `allow`; bit 15 of the returned code). */
+#define FFA_BCO_STEM 0x8000
+int ffa_stem_eligible(int dtype, int kh, int kw, int stride, int cout, int ci_pitch);
+long long ffa_stem_pack_bytes(void);
+long long ffa_stem_stat_rows(int B, int Ho, int Wo);
+int ffa_stem_pack(const float* w_oihw, const float* scale, void* dst, int O, int I, ffa_stream_t stream);
+int ffa_stem_conv7x7(const void* in, const void* w_stem, const float* bias, void* out, float* stat_partials, int B, int Hi,
+                     int Wi, int Ci, int Ho, int Wo, int Co, int relu, ffa_stream_t stream);
 int ffa_conv_row_group(int kh);
 long long ffa_pack_conv_weight_bytes(int dtype, int co_rows, int ci_pitch, int kh, int kw);
 /* OIHW f32 master weight -> kernel operand.  transpose=1 builds the dgrad operand (rows = input
