@@ -54,6 +54,7 @@ struct WgradArgs {
   // layer folded into the consumer): the staged x pieces are rewritten accordingly, padding stays zero
   const float* pro_sc;
   const float* pro_sh;
+  int ci_real;  // real input channels (<= Ci): the stem's 8-channel form needs <= 8
 };
 
 // WCO x WCI waves own distinct (co, ci) sub-tiles; WK further waves split the tile's k-steps (pixels) and
@@ -1437,6 +1438,187 @@ __global__ void __launch_bounds__(512) conv3x3_wgrad64_kernel(WgradArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stem weight gradient, second form (round 3; <= 8 real input channels; FFA_STEM_WGRAD8=0 restores stem_wgrad_kernel):
+// conv7x7_stem_kernel's observation applied to dW = dy^T x -- only the first 8 channels (16 bytes) of an input pixel are
+// staged (LDS-DMA gathers one piece per pixel), so the 16 columns of a v_mfma_f32_16x16x32_bf16 tile are TWO adjacent taps
+// x 8 channels and, the convolution having stride 2, the 32-byte row of output pixel px and tap pair sp is simply the
+// halo bytes of input pixels 2 px + 2 sp, + 1: half the matrix work of the two-taps-x-16-channels form.  Eight waves =
+// two k groups (tile rows 0-3 / 4-7) x four tap pairs; a wave keeps all 64 output channels (4 tiles) x 7 kernel rows = 112
+// accumulator registers and reads every (halo row, pair) fragment ONCE for the up to four tile rows it serves (halo row
+// 2 j + r: rows j, j + 1, ... meet it at r, r - 2, ...).  dy tile and halo by LDS-DMA into a second slot while the first is
+// multiplied; k groups merged through LDS; slab layout [split][Co][49][16] as stem_wgrad_kernel's (same reduce).
+
+struct WgStem8Geom {
+  static constexpr int TH = 8, TW = 32, IH = 2 * TH + 5, IWC = 72;  // 21 halo rows of 69 (padded to 72) 16-byte pixels
+  static constexpr int XP = IH * IWC, YP = TH * TW * 8;             // 16-byte pieces
+  static constexpr int PIECES = XP + YP;
+  static constexpr int NHW = (PIECES + 511) / 512;
+  static constexpr int X_BYTES = XP * 16;
+  static constexpr int SLOT = PIECES * 16;
+  static constexpr int ACC_BYTES = 112 * 64 * 4;  // one wave
+  static constexpr int LDS_BYTES = (2 * SLOT > 4 * ACC_BYTES) ? 2 * SLOT : 4 * ACC_BYTES;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+__global__ void __launch_bounds__(512) stem_wgrad8_kernel(WgradArgs a) {
+  using G = WgStem8Geom;
+  __shared__ __align__(16) unsigned char smem[G::LDS_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kgp = wave >> 2;  // k group: tile rows 4 * kgp .. + 3
+  const int sp = wave & 3;    // tap pair: taps 2 * sp, 2 * sp + 1 of every kernel row
+  const int li = lane & 15, kg = lane >> 4;
+  const int split = blockIdx.y;
+
+  // per 16-byte piece of a slot (x halo, then the dy tile), fixed for the launch: source offset from the tile's origin pixel
+  // in 16-byte units << 14 | dy piece << 13 | no piece << 12 | row << 7 | column
+  int pinfo[G::NHW];
+#pragma unroll
+  for (int k = 0; k < G::NHW; ++k) {
+    const int p = tid + k * 512;
+    if (p < G::XP) {
+      const int hy = p / G::IWC, hx = p % G::IWC;
+      pinfo[k] = (hx < 2 * G::TW + 5) ? (((hy * a.Wi + hx) * 2) << 14 | (hy << 7) | hx) : (1 << 12);
+    } else if (p < G::PIECES) {
+      const int q = (p - G::XP) >> 3, yy = q / G::TW, xx = q % G::TW, sl = (p & 7) ^ (2 * wg64_phi(xx));
+      pinfo[k] = ((yy * a.Wo + xx) * 8 + sl) << 14 | (1 << 13) | (yy << 7) | xx;
+    } else {
+      pinfo[k] = 1 << 12;
+    }
+  }
+  const unsigned char* x_b = static_cast<const unsigned char*>(a.x);
+  const unsigned char* dy_b = static_cast<const unsigned char*>(a.dy);
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(ffa_wgthin_zero16);
+  const bool has_tail = (G::PIECES % 512 == 0) || (wave * 64 + (G::NHW - 1) * 512 < G::PIECES);
+  const int tiles_x = (a.Wo + G::TW - 1) / G::TW, tiles_y = (a.Ho + G::TH - 1) / G::TH;
+  const int npt = a.B * tiles_x * tiles_y;
+
+  auto issue_tile = [&](int t, int slot) {
+    const int tx = t % tiles_x, t2 = t / tiles_x;
+    const int oy0 = (t2 % tiles_y) * G::TH, b = t2 / tiles_y, ox0 = tx * G::TW;
+    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+    const unsigned char* xt = x_b + ((long long)(b * a.Hi + iy0) * a.Wi + ix0) * 32;  // only dereferenced where valid
+    const unsigned char* yt = dy_b + ((long long)(b * a.Ho + oy0) * a.Wo + ox0) * 128;
+#pragma unroll
+    for (int k = 0; k < G::NHW; ++k) {
+      const int info = pinfo[k];
+      const int yy = (info >> 7) & 31, xx = info & 127;
+      const bool mixed = (k == G::XP / 512) && (G::XP % 512 != 0);
+      const bool is_dy = mixed ? (info & (1 << 13)) != 0 : (k * 512 >= G::XP);
+      const bool valid = !(info & (1 << 12)) &&
+                         (is_dy ? (oy0 + yy < a.Ho && ox0 + xx < a.Wo)
+                                : ((unsigned)(iy0 + yy) < (unsigned)a.Hi && (unsigned)(ix0 + xx) < (unsigned)a.Wi));
+      const unsigned char* src = valid ? (is_dy ? yt : xt) + (size_t)(((unsigned)info >> 14) << 4) : zero;
+      const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(
+          smem + slot * G::SLOT + (wave * 64 + k * 512) * 16);
+      if (k + 1 < G::NHW || G::PIECES % 512 == 0) {
+        wgthin_dma16(src, dst);
+      } else if (has_tail) {
+        if (tid + k * 512 < G::PIECES) wgthin_dma16(src, dst);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  ffa_f32x4 acc[4][7];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 7; ++r) acc[mt][r] = ffa_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // lane (li, kg) supplies output pixel kpx = 8 * kg + (li >> 2) (+ 4 for the second read) of a 32-pixel k-step (one tile
+  // row), 8-byte segment li & 3 of a 32-byte row: dy -> a 16-channel tile (slot pair 2 * mt, + 1, swizzled by the column),
+  // x -> the two taps' 2 x 8 channels at input pixel 2 * kpx + 2 * sp
+  const int kpx = 8 * kg + (li >> 2);
+  const int seg = (li & 1) * 8, hbit = (li >> 1) & 1;
+  const int yphi = wg64_phi(kpx);
+  int aoff[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+    aoff[mt] = G::X_BYTES + (kgp * 128 + kpx) * 128 + (((2 * mt + hbit) ^ (2 * yphi)) * 16) + seg;
+  const int boff = ((2 * 4 * kgp) * G::IWC + 2 * kpx + 2 * sp) * 16 + (li & 3) * 8;
+
+  auto tr2 = [&](const unsigned char* p0, int step) {
+    const ffa_s16x4 v0 = lds_read_tr16(p0);
+    const ffa_s16x4 v1 = lds_read_tr16(p0 + step);
+    ffa_u32x4 f;
+    f.x = __builtin_bit_cast(ffa_u32x2, v0).x;
+    f.y = __builtin_bit_cast(ffa_u32x2, v0).y;
+    f.z = __builtin_bit_cast(ffa_u32x2, v1).x;
+    f.w = __builtin_bit_cast(ffa_u32x2, v1).y;
+    return f;
+  };
+
+  const int ntl = (npt - split + a.nsplit - 1) / a.nsplit;
+  if (ntl > 0) {
+    issue_tile(split, 0);
+    int slot = 0;
+    for (int it = 0; it < ntl; ++it) {
+      wgthin_wait_and_meet<0>();
+      if (it + 1 < ntl) issue_tile(split + (it + 1) * a.nsplit, slot ^ 1);
+      const unsigned char* sS = smem + slot * G::SLOT;
+      ffa_u32x4 af[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) af[j][mt] = tr2(sS + aoff[mt] + j * 32 * 128, 4 * 128);
+#pragma unroll
+      for (int h = 0; h < 13; ++h) {  // halo row 2 * (4 * kgp) + h serves tile row j at kernel row r = h - 2 j
+        const ffa_u32x4 bf = tr2(sS + boff + h * (G::IWC * 16), 4 * 2 * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = h - 2 * j;
+          if (r < 0 || r > 6) continue;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            acc[mt][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ffa_bf16x8, af[j][mt]),
+                                                                 __builtin_bit_cast(ffa_bf16x8, bf), acc[mt][r], 0, 0, 0);
+        }
+      }
+      slot ^= 1;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // ---- k group 1 -> LDS, k group 0 adds and writes the block's slab ----
+  float* red = reinterpret_cast<float*>(smem) + (size_t)(wave & 3) * 112 * 64 + lane;
+  if (kgp == 1) {
+    int o = 0;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[(o++) * 64] = acc[mt][r][i];
+  }
+  __syncthreads();
+  if (kgp == 1) return;
+  {
+    int o = 0;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[mt][r][i] += red[(o++) * 64];
+  }
+  // D[row = co][col]: column li -> tap 2 * sp + (li >> 3), channel li & 7; the eighth tap does not exist
+  const int s = 2 * sp + (li >> 3), ch = li & 7;
+  if (s < 7) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int co = mt * 16 + 4 * kg + i;
+          a.slabs[(((size_t)split * a.CoT + co) * 49 + r * 7 + s) * 16 + ch] = acc[mt][r][i];
+        }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 
 struct WgradPlan {
   int wco, wci, wk, th, tw, rg, nsplit, ncob, ncib, CoT, CiT, npt, tiles_x, tiles_y, ring, nslab, stem, thin;
@@ -1656,6 +1838,12 @@ static int launch_wgrad(const WgradArgs& a, const WgradPlan& p, int kh, int kw, 
   } else if (kh == 7) {
     if constexpr (!F32) {
       if (p.stem) {
+        const char* e8 = getenv("FFA_STEM_WGRAD8");
+        if (!(e8 && e8[0] == '0') && a.ci_real <= 8 && a.Ci == 16 && a.Co == 64 && a.pad == 3 && a.Wi <= 3000 && a.Wo <= 1500 &&
+            (long long)a.B * a.Hi * a.Wi * 32 < (1LL << 31)) {
+          hipLaunchKernelGGL(stem_wgrad8_kernel, dim3(1, a.nsplit), dim3(512), 0, stream, a);
+          return ffa_check_launch("stem_wgrad8");
+        }
         hipLaunchKernelGGL((stem_wgrad_kernel<0>), dim3(a.Co / 64, a.nsplit), dim3(512), 0, stream, a);
         return ffa_check_launch("stem_wgrad");
       }
@@ -1703,6 +1891,7 @@ static int wgrad_impl(int dtype, const void* x, const void* x2, int C1, const vo
   a.x = x; a.dy = dy; a.slabs = static_cast<float*>(workspace);
   a.x2 = x2; a.C1 = C1;
   a.pro_sc = pro_scale; a.pro_sh = pro_shift;
+  a.ci_real = Ci_real;
   a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci;
   a.Ho = Ho; a.Wo = Wo; a.Co = Co;
   a.pad = pad;

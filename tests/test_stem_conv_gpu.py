@@ -89,3 +89,32 @@ def test_an_input_with_more_than_eight_channels_keeps_the_generic_kernel(cuda):
     from flairhip import ops, lib as L
     w = torch.randn(64, 10, 7, 7).to(cuda)
     assert not (ops.pack_conv_weight(w, BF, 2, 16).bco & L.BCO_STEM)
+
+
+WG_CASES = [(5, 2, 64, 96), (5, 3, 50, 70), (3, 2, 17, 33), (8, 1, 128, 64), (5, 2, 256, 256)]
+
+
+@pytest.mark.parametrize("cin,B,H,W", WG_CASES, ids=[f"c{c[0]}_b{c[1]}_{c[2]}x{c[3]}" for c in WG_CASES])
+def test_stem_weight_gradient_matches_torch_and_the_older_kernel(cuda, monkeypatch, cin, B, H, W):
+    """stem_wgrad8_kernel (two adjacent taps x 8 channels per 16 MFMA columns; every halo fragment read once for the four
+    tile rows it serves) against torch.nn.grad.conv2d_weight on the bf16-rounded operands and against stem_wgrad_kernel"""
+    from flairhip import ops
+    g = torch.Generator().manual_seed(cin + H * 3 + W)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = torch.randn(B, cin, H, W, generator=g)
+    dy = torch.randn(B, 64, Ho, Wo, generator=g)
+    xd, dyd = to_nhwc(x, cuda, 16), to_nhwc(dy, cuda, 64)
+    got = ops.conv_wgrad(xd, dyd, 64, cin, 7, 7, 2, 3)
+    monkeypatch.setenv("FFA_STEM_WGRAD8", "0")
+    old = ops.conv_wgrad(xd, dyd, 64, cin, 7, 7, 2, 3)
+    ref = torch.nn.grad.conv2d_weight(rq(x), (64, cin, 7, 7), rq(dy), stride=2, padding=3)
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape
+    scale = float(ref.abs().max())
+    tol = 2e-4 * scale * max(1.0, (B * Ho * Wo / 2000) ** 0.5)
+    assert (got.cpu() - ref).abs().max().item() <= tol
+    assert (got - old).abs().max().item() <= tol
+    monkeypatch.delenv("FFA_STEM_WGRAD8")
+    again = ops.conv_wgrad(xd, dyd, 64, cin, 7, 7, 2, 3)
+    torch.cuda.synchronize()
+    assert torch.equal(got, again)
