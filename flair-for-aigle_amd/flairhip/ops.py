@@ -621,15 +621,22 @@ BN_BWD_STAGE_HOOK = None
 
 
 def bn_bwd(x: torch.Tensor, dy: torch.Tensor, y: Optional[torch.Tensor], gamma, beta, mean, rstd, relu: bool,
-           want_dres: bool):
+           want_dres: bool, out_dgamma: Optional[torch.Tensor] = None, out_dbeta: Optional[torch.Tensor] = None):
     """-> (dx, dres or None, dgamma, dbeta).  With relu and y=None the ReLU mask is recomputed from x
-    (only valid when no residual was added before the ReLU)."""
+    (only valid when no residual was added before the ReLU).  out_dgamma / out_dbeta (f32, C elements, contiguous):
+    where the affine gradients are written -- the slots of a data-parallel gradient bucket (flairhip.nn._vec_out)."""
     lib = _l.load()
     C_ = x.shape[-1]
     dev = x.device
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
-    dgb = torch.empty((2, C_), dtype=torch.float32, device=dev)
+    if out_dgamma is not None and out_dbeta is not None:
+        for t in (out_dgamma, out_dbeta):
+            if t.dtype != torch.float32 or t.numel() != C_ or not t.is_contiguous() or t.device != dev:
+                raise ValueError("bn_bwd: output vectors must be contiguous f32 of C elements on the input's device")
+        dgb = (out_dgamma, out_dbeta)
+    else:
+        dgb = torch.empty((2, C_), dtype=torch.float32, device=dev)
     ws = workspace(lib.ffa_bn_workspace_bytes(C_), dev, "bn")
     mode = 0 if not relu else (1 if y is not None else 2)
     if FUSED_BN_BWD_COOP and x.dtype == torch.bfloat16:
