@@ -139,7 +139,8 @@ class HipTrainer:
         # exact_unused: a parameter no rank produced a gradient for keeps grad = None, as under the reference's
         # ddp_find_unused_parameters_true and as in the single-GPU path (AdamW then skips it instead of decaying it);
         # graph mode runs without autograd hooks: the finished gradients are handed to reduce_grads()
-        sync = GradSync(model, hooks=not graph_ddp, exact_unused=True)
+        # graph mode reduces after backward (nothing to overlap with): one collective over all gradients
+        sync = GradSync(model, hooks=not graph_ddp, exact_unused=True, **({"bucket_bytes": 1 << 30} if graph_ddp else {}))
 
         def reduce_now():
             ps = [p for p in model.parameters() if p.grad is not None]
