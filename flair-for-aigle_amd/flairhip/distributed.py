@@ -229,10 +229,27 @@ class GradSync:
             if g.data_ptr() != view.data_ptr():
                 view.copy_(g)
             given.add(p)
-        for b in self._buckets:
-            for p, off in b.slots:
-                if p not in given:
-                    b.flat[off: off + p.numel()].zero_()
+        # slots of parameters without a gradient take part with zeros: merged into contiguous runs (they sit together at
+        # the end of the arrival order: one fill instead of one per parameter), the run list cached per set of givers
+        zkey = (len(given), frozenset(self._index[p] for p in given)) if len(given) < len(self.params) else None
+        if zkey is None:
+            self._zero_runs = (None, [])
+        elif getattr(self, "_zero_runs", (None, None))[0] != zkey:
+            runs = []
+            for bi, b in enumerate(self._buckets):
+                cur = None
+                for p, off in b.slots:
+                    if p not in given:
+                        if cur is not None and cur[1] == off:
+                            cur[1] = off + p.numel()
+                        else:
+                            cur = [off, off + p.numel()]
+                            runs.append((bi, cur))
+                    else:
+                        cur = None
+            self._zero_runs = (zkey, runs)
+        for bi, (lo, hi) in self._zero_runs[1]:
+            self._buckets[bi].flat[lo:hi].zero_()
         if self.world > 1 or self.always_sync:
             backend = dist.get_backend(self.group)
             serial = backend == "gloo"
