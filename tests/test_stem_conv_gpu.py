@@ -27,7 +27,8 @@ def rq(x):
 
 
 # cin, B, H, W, grid cap (0 = default)
-CASES = [(5, 2, 64, 96, 0), (5, 3, 50, 70, 2), (3, 2, 17, 33, 0), (8, 1, 128, 64, 3), (1, 2, 31, 31, 1), (5, 2, 256, 256, 0)]
+CASES = [(5, 2, 64, 96, 0), (5, 3, 50, 70, 2), (3, 2, 17, 33, 0), (8, 1, 128, 64, 3), (1, 2, 31, 31, 1), (5, 2, 256, 256, 0),
+         (5, 1, 7, 9, 0), (4, 3, 8, 8, 0), (5, 1, 1, 1, 0), (2, 2, 2, 130, 0)]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[f"c{c[0]}_b{c[1]}_{c[2]}x{c[3]}_g{c[4]}" for c in CASES])
@@ -91,7 +92,8 @@ def test_an_input_with_more_than_eight_channels_keeps_the_generic_kernel(cuda):
     assert not (ops.pack_conv_weight(w, BF, 2, 16).bco & L.BCO_STEM)
 
 
-WG_CASES = [(5, 2, 64, 96), (5, 3, 50, 70), (3, 2, 17, 33), (8, 1, 128, 64), (5, 2, 256, 256)]
+WG_CASES = [(5, 2, 64, 96), (5, 3, 50, 70), (3, 2, 17, 33), (8, 1, 128, 64), (5, 2, 256, 256), (5, 1, 7, 9), (4, 3, 8, 8),
+            (2, 2, 2, 130)]
 
 
 @pytest.mark.parametrize("cin,B,H,W", WG_CASES, ids=[f"c{c[0]}_b{c[1]}_{c[2]}x{c[3]}" for c in WG_CASES])
